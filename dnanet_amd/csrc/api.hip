@@ -1,0 +1,92 @@
+// C-ABI glue: error text, convolution dispatch. See include/dnanet_hip.h.
+#include <cstdarg>
+#include <cstdio>
+#include "common.h"
+#include "ops.h"
+
+static thread_local char g_err[512] = "";
+
+int dn_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t s) {
+  const int cot = (p.cout_pad % 64 == 0) ? 64 : 32;
+  int ht = 5;
+  if (kh == 3 && kw == 5 && p.H % 6 == 0 && p.H % 5 != 0) ht = 6;
+  if (dtype == DN_BF16) {
+    if (kh == 3 && kw == 5) return conv_igemm_run_bf16_k35(p, ht, cot, s);
+    if (kh == 1 && kw == 3) return conv_igemm_run_bf16_k13(p, ht, cot, s);
+    if (kh == 1 && kw == 1) return conv_igemm_run_bf16_k11(p, ht, cot, s);
+  } else if (dtype == DN_F32) {
+    if (kh == 3 && kw == 5) return conv_igemm_run_f32_k35(p, ht, cot, s);
+    if (kh == 1 && kw == 3) return conv_igemm_run_f32_k13(p, ht, cot, s);
+    if (kh == 1 && kw == 1) return conv_igemm_run_f32_k11(p, ht, cot, s);
+  } else {
+    return dn_set_error(DN_ERR_ARG, "bad dtype %d", dtype);
+  }
+  return dn_set_error(DN_ERR_UNSUPPORTED, "convolution kernel size (%d,%d) is not built (have (3,5), (1,3), (1,1))", kh, kw);
+}
+
+extern "C" {
+
+const char* dn_last_error(void) { return g_err; }
+int dn_abi_version(void) { return 1; }
+
+int dn_conv2d(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
+              int relu, int dtype, void* stream) {
+  DN_CHECK_ARG(x.base && packed_w && y.base, "dn_conv2d: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && x.channels > 0 && y.channels > 0, "dn_conv2d: bad shape N=%d H=%d W=%d", N, H, W);
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d: bad dtype %d", dtype);
+  const int xp = dn_planes(x.channels, dtype), yp = dn_planes(y.channels, dtype);
+  DN_CHECK_ARG(x.plane0 >= 0 && x.plane0 + xp <= x.planes_total, "dn_conv2d: x planes [%d,%d) outside buffer of %d",
+               x.plane0, x.plane0 + xp, x.planes_total);
+  DN_CHECK_ARG(y.plane0 >= 0 && y.plane0 + yp <= y.planes_total, "dn_conv2d: y planes [%d,%d) outside buffer of %d",
+               y.plane0, y.plane0 + yp, y.planes_total);
+  ConvParams p{};
+  p.x = x.base; p.x_planes_total = x.planes_total; p.x_plane0 = x.plane0; p.x_nplanes = xp; p.x_gplanes = 1 << 30; p.x_wmul = 1;
+  p.w = packed_w; p.bias = bias;
+  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.N = N; p.H = H; p.W = W; p.nchunk = xp; p.cout_pad = dn_channel_pad(y.channels); p.relu = relu;
+  return run_igemm(p, kh, kw, dtype, (hipStream_t)stream);
+}
+
+int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2, dn_tensor y, int N, int H, int Win,
+                          int dtype, void* stream) {
+  DN_CHECK_ARG(x.base && packed_w && y.base, "dn_conv_transpose_1x2: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && Win > 0, "dn_conv_transpose_1x2: bad shape");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_transpose_1x2: bad dtype %d", dtype);
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  const int xp = dn_planes(x.channels, dtype), yp = dn_planes(y.channels, dtype);
+  DN_CHECK_ARG(x.plane0 + xp <= x.planes_total && y.plane0 + yp <= y.planes_total, "dn_conv_transpose_1x2: planes outside buffer");
+  const int gsize = dn_channel_pad(y.channels);
+  ConvParams p{};
+  p.x = x.base; p.x_planes_total = x.planes_total; p.x_plane0 = x.plane0; p.x_nplanes = xp; p.x_gplanes = 1 << 30; p.x_wmul = 1;
+  p.w = packed_w; p.bias = bias2;
+  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = gsize / epr; p.y_wmul = 2;
+  p.N = N; p.H = H; p.W = Win; p.nchunk = xp; p.cout_pad = 2 * gsize; p.relu = 0;
+  return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);
+}
+
+int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx, int N, int H, int Win, int dtype,
+                                void* stream) {
+  DN_CHECK_ARG(dy.base && packed_w && dx.base, "dn_conv_transpose_1x2_dgrad: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && Win > 0, "dn_conv_transpose_1x2_dgrad: bad shape");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_transpose_1x2_dgrad: bad dtype %d", dtype);
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  const int yp = dn_planes(dy.channels, dtype), xp = dn_planes(dx.channels, dtype);
+  DN_CHECK_ARG(dy.plane0 + yp <= dy.planes_total && dx.plane0 + xp <= dx.planes_total, "dn_conv_transpose_1x2_dgrad: planes outside buffer");
+  const int gsize = dn_channel_pad(dy.channels);
+  ConvParams p{};
+  p.x = dy.base; p.x_planes_total = dy.planes_total; p.x_plane0 = dy.plane0; p.x_nplanes = yp; p.x_gplanes = gsize / epr; p.x_wmul = 2;
+  p.w = packed_w; p.bias = nullptr;
+  p.y = dx.base; p.y_planes_total = dx.planes_total; p.y_plane0 = dx.plane0; p.y_nplanes = xp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.N = N; p.H = H; p.W = Win; p.nchunk = 2 * (gsize / epr); p.cout_pad = dn_channel_pad(dx.channels); p.relu = 0;
+  return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

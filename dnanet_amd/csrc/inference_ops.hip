@@ -1,0 +1,246 @@
+// Memory-bound stages of the U-Net forward pass on plane-record buffers (see common.h):
+//   first convolution (Cin = 1, raw fp32 RFU input), MaxPool2d((1,2)), 1x1 head + sigmoid,
+//   weight packing for the implicit-GEMM kernel.
+// Reference: DNAnet/models/segmentation/unet_architecture.py:14-20 (first conv), :37 (pool),
+// :94-97 (head); DNAnet/models/segmentation/trainable_unet.py:401-409 (sigmoid).
+#include "common.h"
+#include "ops.h"
+
+// ------------------------------------------------------------------------------------------------
+// first convolution: x [N][H][W] fp32 -> y planes, one thread = one output record (EPR channels)
+// wf: [taps][cpad] fp32 (already multiplied by the folded BN scale when inference), bias [cpad]
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ wf,
+                                                         const float* __restrict__ bias, unsigned char* y,
+                                                         int y_planes_total, int y_plane0, int N, int H, int W,
+                                                         int cpad, int relu) {
+  constexpr int EPR = RecTraits<T>::EPR, TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
+  __shared__ float ws[TAPS * EPR + EPR];
+  const int plane = blockIdx.y;
+  for (int i = threadIdx.x; i < TAPS * EPR; i += blockDim.x) ws[i] = wf[(i / EPR) * cpad + plane * EPR + (i % EPR)];
+  if (threadIdx.x < EPR) ws[TAPS * EPR + threadIdx.x] = bias ? bias[plane * EPR + threadIdx.x] : 0.f;
+  __syncthreads();
+  const long total = (long)N * H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(pix % W);
+    const int h = (int)((pix / W) % H);
+    const long n = pix / ((long)W * H);
+    float acc[EPR];
+#pragma unroll
+    for (int c = 0; c < EPR; ++c) acc[c] = ws[TAPS * EPR + c];
+#pragma unroll
+    for (int dh = 0; dh < KH; ++dh) {
+      const int hh = h + dh - PH;
+      if (hh < 0 || hh >= H) continue;
+#pragma unroll
+      for (int dw = 0; dw < KW; ++dw) {
+        const int ww = w + dw - PW;
+        if (ww < 0 || ww >= W) continue;
+        const float xv = x[(n * H + hh) * W + ww];
+#pragma unroll
+        for (int c = 0; c < EPR; ++c) acc[c] = fmaf(xv, ws[(dh * KW + dw) * EPR + c], acc[c]);
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int c = 0; c < EPR; ++c) acc[c] = fmaxf(acc[c], 0.f);
+    }
+    unsigned char* dst = y + (((n * y_planes_total + y_plane0 + plane) * H + h) * (long)W + w) * 32;
+    *(uint4*)dst = Piece<T>::pack(acc);
+    *(uint4*)(dst + 16) = Piece<T>::pack(acc + Piece<T>::N);
+  }
+}
+
+template <typename T>
+static int conv_first_t(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout,
+                        int kh, int kw, int relu, hipStream_t s) {
+  constexpr int EPR = RecTraits<T>::EPR;
+  const int nplanes = (cout + EPR - 1) / EPR;
+  const int cpad = dn_channel_pad(cout);
+  const long total = (long)N * H * W;
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 4096), nplanes);
+#define LAUNCH(KH, KW) hipLaunchKernelGGL((conv_first_kernel<T, KH, KW>), grid, dim3(256), 0, s, x, wf, bias, \
+    (unsigned char*)y.base, y.planes_total, y.plane0, N, H, W, cpad, relu)
+  if (kh == 3 && kw == 5) LAUNCH(3, 5);
+  else if (kh == 1 && kw == 3) LAUNCH(1, 3);
+  else if (kh == 1 && kw == 1) LAUNCH(1, 1);
+  else return dn_set_error(DN_ERR_UNSUPPORTED, "conv_first: kernel size (%d,%d) not built", kh, kw);
+#undef LAUNCH
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d((1,2)): one thread = one 16-byte output piece
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const unsigned char* x, int x_planes_total, int x_plane0,
+                                                      unsigned char* y, int y_planes_total, int y_plane0, int nplanes,
+                                                      int N, int H, int Wout) {
+  const long total = (long)N * nplanes * H * Wout * 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int pc = (int)(i & 1);
+    long r = i >> 1;
+    const int w = (int)(r % Wout); r /= Wout;
+    const int h = (int)(r % H); r /= H;
+    const int pl = (int)(r % nplanes);
+    const long n = r / nplanes;
+    const unsigned char* src = x + ((((n * x_planes_total + x_plane0 + pl) * H + h) * (long)(2 * Wout)) + 2 * w) * 32 + 16 * pc;
+    const uint4 a = *(const uint4*)src, b = *(const uint4*)(src + 32);
+    float fa[Piece<T>::N], fb[Piece<T>::N];
+    Piece<T>::unpack(a, fa); Piece<T>::unpack(b, fb);
+#pragma unroll
+    for (int k = 0; k < Piece<T>::N; ++k) fa[k] = fmaxf(fa[k], fb[k]);
+    *(uint4*)(y + ((((n * y_planes_total + y_plane0 + pl) * H + h) * (long)Wout) + w) * 32 + 16 * pc) = Piece<T>::pack(fa);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: logits[n,h,w] = b + sum_c x[n,c,h,w] * w[c];  probs = sigmoid(logits)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void head_kernel(const unsigned char* x, int x_planes_total, int x_plane0, int nplanes,
+                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                   float* logits, float* probs, int N, int H, int W) {
+  constexpr int EPR = RecTraits<T>::EPR, PN = Piece<T>::N;
+  const long total = (long)N * H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
+    const long hw = pix % ((long)H * W);
+    const long n = pix / ((long)H * W);
+    float acc = b[0];
+    for (int pl = 0; pl < nplanes; ++pl) {
+      const unsigned char* src = x + (((n * x_planes_total + x_plane0 + pl) * (long)H * W) + hw) * 32;
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        float f[PN];
+        Piece<T>::unpack(*(const uint4*)(src + 16 * pc), f);
+#pragma unroll
+        for (int k = 0; k < PN; ++k) acc = fmaf(f[k], w[pl * EPR + pc * PN + k], acc);
+      }
+    }
+    if (logits) logits[pix] = acc;
+    if (probs) probs[pix] = 1.f / (1.f + expf(-acc));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: canonical fp32 parameter -> [nchunk][taps][rows_pad][EPR] of T
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                          T* out, int cout, int cin, int taps, int mode, int rows_pad,
+                                                          int nchunk, int gsize) {
+  constexpr int EPR = RecTraits<T>::EPR;
+  const long total = (long)nchunk * taps * rows_pad * EPR;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % EPR);
+    long r = i / EPR;
+    const int row = (int)(r % rows_pad); r /= rows_pad;
+    const int tap = (int)(r % taps);
+    const int ck = (int)(r / taps);
+    float v = 0.f;
+    if (mode == DN_PACK_FWD) {                 // rows = co, K = ci
+      const int co = row, ci = ck * EPR + e;
+      if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + tap] * (scale ? scale[co] : 1.f);
+    } else if (mode == DN_PACK_DGRAD) {        // rows = ci, K = co, taps flipped
+      const int ci = row, co = ck * EPR + e;
+      if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + (taps - 1 - tap)];
+    } else if (mode == DN_PACK_CONVT_FWD) {    // w: [cin][cout][1][2]; rows = k*gsize + co, K = ci
+      const int k = row / gsize, co = row % gsize, ci = ck * EPR + e;
+      if (k < 2 && co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
+    } else {                                   // DN_PACK_CONVT_DGRAD: rows = ci, K = (k, co) virtual planes
+      const int gpl = gsize / EPR;
+      const int k = ck / gpl, co = (ck % gpl) * EPR + e, ci = row;
+      if (k < 2 && co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
+    }
+    out[i] = dn_from_float<T>(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int dn_conv_first(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout, int kh,
+                  int kw, int relu, int dtype, void* stream) {
+  DN_CHECK_ARG(x && wf && y.base, "dn_conv_first: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && cout > 0, "dn_conv_first: bad shape N=%d H=%d W=%d cout=%d", N, H, W, cout);
+  DN_CHECK_ARG(y.channels == cout, "dn_conv_first: y.channels=%d != cout=%d", y.channels, cout);
+  if (dtype == DN_BF16) return conv_first_t<__bf16>(x, wf, bias, y, N, H, W, cout, kh, kw, relu, (hipStream_t)stream);
+  if (dtype == DN_F32) return conv_first_t<float>(x, wf, bias, y, N, H, W, cout, kh, kw, relu, (hipStream_t)stream);
+  return dn_set_error(DN_ERR_ARG, "dn_conv_first: bad dtype %d", dtype);
+}
+
+int dn_maxpool_1x2(dn_tensor x, dn_tensor y, int N, int H, int Wout, int dtype, void* stream) {
+  DN_CHECK_ARG(x.base && y.base, "dn_maxpool_1x2: null pointer");
+  DN_CHECK_ARG(x.channels == y.channels && N > 0 && H > 0 && Wout > 0, "dn_maxpool_1x2: bad shape");
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  const int nplanes = (x.channels + epr - 1) / epr;
+  const long total = (long)N * nplanes * H * Wout * 2;
+  const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 8192);
+  if (dtype == DN_BF16)
+    hipLaunchKernelGGL(maxpool_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x.base,
+                       x.planes_total, x.plane0, (unsigned char*)y.base, y.planes_total, y.plane0, nplanes, N, H, Wout);
+  else if (dtype == DN_F32)
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x.base,
+                       x.planes_total, x.plane0, (unsigned char*)y.base, y.planes_total, y.plane0, nplanes, N, H, Wout);
+  else return dn_set_error(DN_ERR_ARG, "dn_maxpool_1x2: bad dtype %d", dtype);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+int dn_head_1x1(dn_tensor x, const float* w, const float* b, float* logits, float* probs, int N, int H, int W, int dtype,
+                void* stream) {
+  DN_CHECK_ARG(x.base && w && b && (logits || probs), "dn_head_1x1: null pointer");
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  const int nplanes = (x.channels + epr - 1) / epr;
+  const long total = (long)N * H * W;
+  const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 8192);
+  if (dtype == DN_BF16)
+    hipLaunchKernelGGL(head_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x.base,
+                       x.planes_total, x.plane0, nplanes, w, b, logits, probs, N, H, W);
+  else if (dtype == DN_F32)
+    hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x.base,
+                       x.planes_total, x.plane0, nplanes, w, b, logits, probs, N, H, W);
+  else return dn_set_error(DN_ERR_ARG, "dn_head_1x1: bad dtype %d", dtype);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+long dn_packed_weight_bytes(int cout, int cin, int kh, int kw, int mode, int dtype) {
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  int rows_pad, nchunk, taps = kh * kw;
+  if (mode == DN_PACK_FWD) { rows_pad = dn_channel_pad(cout); nchunk = (cin + epr - 1) / epr; }
+  else if (mode == DN_PACK_DGRAD) { rows_pad = dn_channel_pad(cin); nchunk = (cout + epr - 1) / epr; }
+  else if (mode == DN_PACK_CONVT_FWD) { rows_pad = 2 * dn_channel_pad(cout); nchunk = (cin + epr - 1) / epr; taps = 1; }
+  else if (mode == DN_PACK_CONVT_DGRAD) { rows_pad = dn_channel_pad(cin); nchunk = 2 * (dn_channel_pad(cout) / epr); taps = 1; }
+  else return -1;
+  return (long)nchunk * taps * rows_pad * 32;
+}
+
+int dn_pack_weight(const float* w, const float* scale, void* packed, int cout, int cin, int kh, int kw, int mode, int dtype,
+                   void* stream) {
+  DN_CHECK_ARG(w && packed, "dn_pack_weight: null pointer");
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  int rows_pad, nchunk, taps = kh * kw, gsize = dn_channel_pad(cout);
+  if (mode == DN_PACK_FWD) { rows_pad = dn_channel_pad(cout); nchunk = (cin + epr - 1) / epr; }
+  else if (mode == DN_PACK_DGRAD) { rows_pad = dn_channel_pad(cin); nchunk = (cout + epr - 1) / epr; }
+  else if (mode == DN_PACK_CONVT_FWD) { rows_pad = 2 * gsize; nchunk = (cin + epr - 1) / epr; taps = 1; }
+  else if (mode == DN_PACK_CONVT_DGRAD) { rows_pad = dn_channel_pad(cin); nchunk = 2 * (gsize / epr); taps = 1; }
+  else return dn_set_error(DN_ERR_ARG, "dn_pack_weight: bad mode %d", mode);
+  const long total = (long)nchunk * taps * rows_pad * epr;
+  const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 4096);
+  if (dtype == DN_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, scale, (__bf16*)packed,
+                       cout, cin, taps, mode, rows_pad, nchunk, gsize);
+  else if (dtype == DN_F32)
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, scale, (float*)packed,
+                       cout, cin, taps, mode, rows_pad, nchunk, gsize);
+  else return dn_set_error(DN_ERR_ARG, "dn_pack_weight: bad dtype %d", dtype);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+}  // extern "C"

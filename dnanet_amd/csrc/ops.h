@@ -1,0 +1,12 @@
+// internal: public C ABI + helpers shared by the translation units of libdnanet_hip.so
+#pragma once
+#include <algorithm>
+#include "dnanet_hip.h"
+#include "conv_igemm.h"
+
+int conv_igemm_run_bf16_k35(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_bf16_k13(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_bf16_k11(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_f32_k35(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_f32_k13(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_f32_k11(const ConvParams& p, int ht, int cot, hipStream_t s);

@@ -1,0 +1,128 @@
+"""ctypes binding of ``libdnanet_hip.so`` (C ABI in ``include/dnanet_hip.h``).
+
+The library is built in-tree by ``dnanet_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There is
+no CPU fallback: if the shared object is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+
+import torch
+
+F32, BF16 = 0, 1
+PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdnanet_hip.so")
+
+
+class DnTensor(Structure):
+    _fields_ = [("base", c_void_p), ("planes_total", c_int), ("plane0", c_int), ("channels", c_int)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `make -C dnanet_amd/csrc` (or __graft_entry__.build()). "
+            "dnanet_amd has no CPU fallback.")
+    return ctypes.CDLL(_LIB_PATH)
+
+
+lib = _load()
+
+_P = c_void_p
+_SIGS = {
+    "dn_last_error": (c_char_p, []),
+    "dn_abi_version": (c_int, []),
+    "dn_packed_weight_bytes": (c_long, [c_int] * 6),
+    "dn_pack_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "dn_conv_first": (c_int, [_P, _P, _P, DnTensor] + [c_int] * 8 + [_P]),
+    "dn_conv2d": (c_int, [DnTensor, _P, _P, DnTensor] + [c_int] * 7 + [_P]),
+    "dn_conv_transpose_1x2": (c_int, [DnTensor, _P, _P, DnTensor, c_int, c_int, c_int, c_int, _P]),
+    "dn_conv_transpose_1x2_dgrad": (c_int, [DnTensor, _P, DnTensor, c_int, c_int, c_int, c_int, _P]),
+    "dn_maxpool_1x2": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, c_int, _P]),
+    "dn_head_1x1": (c_int, [DnTensor, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+}
+
+
+def _bind():
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+_bind()
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc: int):
+    if rc != 0:
+        raise HipError(f"libdnanet_hip error {rc}: {lib.dn_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device, contiguous tensor required"
+    return t.data_ptr()
+
+
+def epr(dtype: int) -> int:
+    return 16 if dtype == BF16 else 8
+
+
+def torch_dtype(dtype: int):
+    return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+def channel_pad(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def planes(c: int, dtype: int) -> int:
+    e = epr(dtype)
+    return (c + e - 1) // e
+
+
+class PlaneBuffer:
+    """A plane-record activation buffer [N][planes][H][W][epr] owned by torch's allocator."""
+
+    def __init__(self, n: int, planes_total: int, h: int, w: int, dtype: int, device, zero: bool = False):
+        self.n, self.planes_total, self.h, self.w, self.dtype = n, planes_total, h, w, dtype
+        alloc = torch.zeros if zero else torch.empty
+        self.data = alloc((n, planes_total, h, w, epr(dtype)), dtype=torch_dtype(dtype), device=device)
+
+    def ref(self, channels: int, plane0: int = 0) -> DnTensor:
+        assert plane0 + planes(channels, self.dtype) <= self.planes_total
+        return DnTensor(self.data.data_ptr(), self.planes_total, plane0, channels)
+
+    # conversions for tests / boundaries (torch ops, not on the hot path)
+    @staticmethod
+    def from_nchw(x: torch.Tensor, dtype: int) -> "PlaneBuffer":
+        n, c, h, w = x.shape
+        e = epr(dtype)
+        p = planes(c, dtype)
+        buf = PlaneBuffer(n, p, h, w, dtype, x.device, zero=True)
+        xp = torch.zeros((n, p * e, h, w), dtype=torch.float32, device=x.device)
+        xp[:, :c] = x
+        buf.data.copy_(xp.view(n, p, e, h, w).permute(0, 1, 3, 4, 2))
+        return buf
+
+    def to_nchw(self, channels: int, plane0: int = 0) -> torch.Tensor:
+        e = epr(self.dtype)
+        p = planes(channels, self.dtype)
+        d = self.data[:, plane0:plane0 + p].float().permute(0, 1, 4, 2, 3).reshape(self.n, p * e, self.h, self.w)
+        return d[:, :channels].contiguous()

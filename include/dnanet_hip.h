@@ -1,0 +1,86 @@
+/* dnanet_hip.h -- C ABI of libdnanet_hip.so: the MI355X (gfx950) kernels behind DNANet's U-Net
+ * peak-segmentation hot path.
+ *
+ * The reference (NetherlandsForensicInstitute/DNANet) is pure Python on torch.nn; its "FFI" for
+ * this path is the set of torch.nn / torch.optim operators it calls.  Each entry point below
+ * replaces one of those operator calls and cites it (paths relative to the reference root).
+ * Signatures are plain C: device pointers, sizes, an opaque hipStream_t (void*).  No entry point
+ * allocates or frees device memory; workspaces are passed in.  All return 0 on success, non-zero
+ * on error (dn_last_error() gives the text).  Kernels are launched on the given stream and the
+ * call returns without synchronising.
+ *
+ * Activation layout ("plane-record", internal to the library, never escapes to the caller's API):
+ *   buffer[N][planes_total][H][W][32 bytes], one 32-byte record = 16 bf16 or 8 fp32 channels.
+ *   A logical tensor of C channels occupies planes [plane0, plane0 + ceil(C/epr)) of a buffer; the
+ *   skip-concat of DecoderBlock (unet_architecture.py:62) is two tensors in one buffer (zero copy).
+ *   Channels past C inside the last plane are kept at zero by every kernel.
+ * Per-channel vectors (bias, scale, shift, mean ...) are fp32 arrays of dn_channel_pad(C) floats,
+ * zero past C.
+ */
+#ifndef DNANET_HIP_H
+#define DNANET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_DTYPE_F32 0   /* fp32 storage, v_mfma_f32_32x32x2_f32 */
+#define DN_DTYPE_BF16 1  /* bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+
+#define DN_PACK_FWD 0          /* Conv2d weight [Cout][Cin][KH][KW] for the forward GEMM */
+#define DN_PACK_DGRAD 1        /* same weight, flipped/transposed, for the data gradient */
+#define DN_PACK_CONVT_FWD 2    /* ConvTranspose2d weight [Cin][Cout][1][2] as a 1x1 GEMM to 2*Cout */
+#define DN_PACK_CONVT_DGRAD 3  /* its data gradient: 1x1 GEMM from the two output columns to Cin */
+
+typedef struct dn_tensor {
+  void* base;        /* device pointer to the buffer */
+  int planes_total;  /* planes per image in the buffer */
+  int plane0;        /* first plane of this tensor */
+  int channels;      /* logical channel count C */
+} dn_tensor;
+
+const char* dn_last_error(void);
+int dn_abi_version(void);
+static inline int dn_channel_pad(int c) { return (c + 31) / 32 * 32; }
+static inline int dn_planes(int c, int dtype) { int e = dtype == DN_DTYPE_BF16 ? 16 : 8; return (c + e - 1) / e; }
+
+/* ---- parameter staging ------------------------------------------------------------------- */
+/* Bytes of the packed image of a weight (see DN_PACK_*). */
+long dn_packed_weight_bytes(int cout, int cin, int kh, int kw, int mode, int dtype);
+/* Pack a canonical fp32 parameter (state_dict layout, unet_architecture.py:14-20,54-57) into the
+ * GEMM image; `scale` (nullable, [cout]) folds eval-mode BatchNorm (unet_architecture.py:17,21):
+ * w' = w * gamma / sqrt(running_var + eps). */
+int dn_pack_weight(const float* w, const float* scale, void* packed, int cout, int cin, int kh, int kw, int mode,
+                   int dtype, void* stream);
+
+/* ---- forward operators -------------------------------------------------------------------- */
+/* nn.Conv2d(1, cout, (kh,kw), padding=k//2) on the raw fp32 input x[N][1][H][W]
+ * (unet_architecture.py:14-16 for encoders.0; trainable_unet.py:70-79 for the input).
+ * wf: [kh*kw][dn_channel_pad(cout)] fp32 (BN scale already folded in for inference), bias likewise. */
+int dn_conv_first(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout, int kh,
+                  int kw, int relu, int dtype, void* stream);
+/* nn.Conv2d(cin, cout, (kh,kw), padding=k//2) [+ folded BatchNorm2d + ReLU when relu=1]
+ * (unet_architecture.py:14-21): y = act(conv(x, packed_w) + bias).  packed_w from DN_PACK_FWD, or
+ * DN_PACK_DGRAD to compute the data gradient (then x = dy, cin/cout swapped by the caller). */
+int dn_conv2d(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
+              int relu, int dtype, void* stream);
+/* nn.ConvTranspose2d(cin, cout, (1,2), stride (1,2)) (unet_architecture.py:54-57):
+ * y[n,co,h,2w+k] = bias[co] + sum_ci x[n,ci,h,w] * W[ci,co,0,k].  x is N x H x Win, y is N x H x 2*Win.
+ * packed_w from DN_PACK_CONVT_FWD; bias2: [2*dn_channel_pad(cout)] = bias repeated per k. */
+int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2, dn_tensor y, int N, int H, int Win,
+                          int dtype, void* stream);
+/* Data gradient of the above: dx[n,ci,h,w] = sum_{k,co} dy[n,co,h,2w+k] * W[ci,co,0,k]; packed_w from
+ * DN_PACK_CONVT_DGRAD. */
+int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx, int N, int H, int Win, int dtype,
+                                void* stream);
+/* nn.MaxPool2d((1,2)) (unet_architecture.py:37): y[n,c,h,w] = max(x[n,c,h,2w], x[n,c,h,2w+1]). */
+int dn_maxpool_1x2(dn_tensor x, dn_tensor y, int N, int H, int Wout, int dtype, void* stream);
+/* nn.Conv2d(C, 1, 1) head (unet_architecture.py:94-97) and torch.sigmoid (trainable_unet.py:409):
+ * logits/probs are [N][1][H][W] fp32, either may be null. w: [dn_channel_pad(C)], b: [1]. */
+int dn_head_1x1(dn_tensor x, const float* w, const float* b, float* logits, float* probs, int N, int H, int W, int dtype,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNANET_HIP_H */
