@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         for (int k = 0; k < SB; ++k) {
           const int tap = (it0 + k) * TPI + w_tap;
           v[k] = make_uint4(0, 0, 0, 0);
-          if (it0 + k < W_ITERS && tap < TAPS) v[k] = *(const uint4*)(wsrc + (long)tap * p.cout_pad * 32 + w_goff);
+          if (it0 + k < W_ITERS && tap < TAPS) v[k] = *(const uint4*)(wsrc + (long)((it0 + k) * TPI) * p.cout_pad * 32 + w_goff);
         }
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
