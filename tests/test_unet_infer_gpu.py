@@ -1,0 +1,74 @@
+"""Whole-network eval-mode parity: HIP path vs the golden fixtures made by the reference modules and
+vs the CPU oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+# stated tolerances on logits, relative to max|logit| of the case
+TOL = {"fp32": 2e-5, "bf16": 4e-2}
+
+
+def _model(g, dtype, dev):
+    from dnanet_amd.unet import HipUNet
+    m = HipUNet(int(g["depth"]), tuple(int(v) for v in g["kernel"]), int(g["filters"]), dev, dtype=dtype)
+    missing = m.load_state_dict(g["sd0"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m.eval()
+    return m
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", golden_names())
+def test_logits_vs_reference_fixture(gpu_device, name, dtype):
+    g = load_golden(name)
+    m = _model(g, dtype, gpu_device)
+    x = torch.from_numpy(g["x"]).to(gpu_device)
+    logits, probs = m.infer(x)
+    ref = torch.from_numpy(g["logits_eval"])
+    scale = float(ref.abs().max())
+    err = float((logits.cpu() - ref).abs().max()) / scale
+    assert err < TOL[dtype], f"{name} {dtype}: max rel err {err:.3e}"
+    assert torch.allclose(probs.cpu(), torch.sigmoid(logits.cpu()), atol=1e-6)
+    # segmentation masks (sigmoid >= 0.5, allele_callers.py:80): identical in fp32 mode except
+    # where the reference logit itself sits within the tolerance of the threshold
+    mask, ref_mask = probs.cpu() >= 0.5, torch.sigmoid(ref) >= 0.5
+    decided = ref.abs() > TOL[dtype] * scale
+    assert torch.equal(mask[decided], ref_mask[decided])
+    if dtype == "fp32":
+        assert int((mask != ref_mask).sum()) <= 2
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("h", [5, 6])
+def test_shipped_config_vs_oracle(gpu_device, dtype, h):
+    """depth 4, kernel (3,5), 32 filters (config/models/unet.yaml:1-6) at full scan length."""
+    from oracle import unet_oracle as O
+    from dnanet_amd.unet import HipUNet
+    sd = O.init_state_dict(4, (3, 5), 32, seed=h, randomize_bn_stats=True)
+    g = torch.Generator().manual_seed(100 + h)
+    x = (torch.rand(2, 1, h, 4096, generator=g) ** 6 * 12000).round()
+    with torch.no_grad():
+        ref = O.unet_forward(sd, x, train=False)
+    m = HipUNet(4, (3, 5), 32, gpu_device, dtype=dtype)
+    m.load_state_dict(sd)
+    m.eval()
+    logits = m(x.to(gpu_device)).cpu()
+    err = float((logits - ref).abs().max()) / float(ref.abs().max())
+    assert err < TOL[dtype], f"max rel err {err:.3e}"
+
+
+def test_batch_invariance_and_chunking(gpu_device):
+    """predict_batch feeds the whole dataset as one batch (evaluate.py:47); chunking it must not change results."""
+    from dnanet_amd.unet import HipUNet
+    m = HipUNet(2, (3, 5), 8, gpu_device, dtype="fp32")
+    m.eval()
+    x = torch.rand(7, 1, 5, 64, device=gpu_device) * 1000
+    a = m(x)
+    m.MAX_CHUNK = 3
+    b = m(x)
+    assert torch.equal(a, b)
+    assert torch.equal(m(x[2:3]), a[2:3])
