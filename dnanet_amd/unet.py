@@ -44,6 +44,7 @@ class HipUNet(ParameterTree):
         self.dtype = parse_dtype(dtype)
         self._eval_cache = None
         self._eval_cache_version = None
+        self.profile = None     # set to a list to collect (kernel tag, flops, start event, end event) per conv launch
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -133,7 +134,25 @@ class HipUNet(ParameterTree):
         self._eval_cache = cache
         self._eval_cache_version = self._versions()
 
+    def conv_kernel_tag(self, cout: int, h: int) -> str:
+        """Name of the conv_igemm instantiation the library dispatches to (api.hip: run_igemm)."""
+        kh, kw = self.kernel_size
+        cot = 64 if hip.channel_pad(cout) % 64 == 0 else 32
+        ht = 6 if ((kh, kw) == (3, 5) and h % 6 == 0 and h % 5 != 0) else 5
+        return f"conv_igemm<{'bf16' if self.dtype == BF16 else 'f32'},{kh}x{kw},ht{ht},cot{cot}>"
+
     def _conv(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1):
+        if self.profile is not None and u.cin != 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._conv_launch(u, entry, src, dst, n, h, w, relu)
+            e1.record()
+            kh, kw = self.kernel_size
+            self.profile.append((self.conv_kernel_tag(u.cout, h), 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
+        else:
+            self._conv_launch(u, entry, src, dst, n, h, w, relu)
+
+    def _conv_launch(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1):
         kh, kw = self.kernel_size
         if u.cin == 1:
             hip.check(hip.lib.dn_conv_first(hip.ptr(src), hip.ptr(entry["wf"]), hip.ptr(entry["bias"]), dst, n, h, w,
