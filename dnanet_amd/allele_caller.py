@@ -1,0 +1,95 @@
+"""Nearest-base-pair allele caller: the consumer of the U-Net's probability maps.
+
+Same contract as ``NearestBasePairCaller`` (reference ``DNAnet/allele_callers.py:38-125``): per dye row,
+pixels with probability >= 0.5 (``:80``) are grouped into runs of consecutive scan columns (``:87``); a
+run's mean base pair (``:90``) selects the panel allele with the nearest base pair on that dye
+(``:122-123``, first-listed wins a tie); the allele's height is the highest RFU seen in any of its runs
+(``:94-98``).  This implementation finds runs with one vectorised edge detection per dye and the nearest
+allele by binary search on the dye's sorted base-pair table instead of Python loops over pixels/alleles.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .data import Allele, Marker, Panel
+from .prediction import Prediction
+
+LOGGER = logging.getLogger("dnanet")
+
+NON_AUTOSOMAL_MARKERS = ["AMEL", "DYS391", "DYS576", "DYS570"]   # allele_callers.py:15
+
+
+class _DyeTable:
+    """Sorted base pairs of one dye with their (marker, allele) names and panel order."""
+
+    def __init__(self, mapping: Dict[float, Tuple[str, str]]):
+        keys = list(mapping.keys())
+        bps = np.asarray(keys, dtype=np.float64)
+        self.order = np.argsort(bps, kind="stable")     # order[j] = position in the panel (tie-break)
+        self.bps = bps[self.order]
+        self.names = [mapping[keys[i]] for i in self.order]
+
+    def nearest(self, bp: float) -> Tuple[str, str]:
+        i = int(np.searchsorted(self.bps, bp))
+        cands = [j for j in (i - 1, i) if 0 <= j < len(self.bps)]
+        # equal base pairs sit next to each other after the stable sort; widen to all equals
+        best = min(cands, key=lambda j: (abs(self.bps[j] - bp), self.order[j]))
+        d = abs(self.bps[best] - bp)
+        j = best
+        while j - 1 >= 0 and abs(self.bps[j - 1] - bp) == d:
+            j -= 1
+            if self.order[j] < self.order[best]:
+                best = j
+        j = best
+        while j + 1 < len(self.bps) and abs(self.bps[j + 1] - bp) == d:
+            j += 1
+            if self.order[j] < self.order[best]:
+                best = j
+        return self.names[best]
+
+
+class NearestBasePairCaller:
+    def __init__(self):
+        self._tables: Dict[int, Dict[int, _DyeTable]] = {}
+
+    def _table(self, panel: Panel, dye: int) -> _DyeTable:
+        per_panel = self._tables.setdefault(id(panel), {})
+        if dye not in per_panel:
+            per_panel[dye] = _DyeTable(panel.dye_bp_to_allele_mapping[dye])
+        return per_panel[dye]
+
+    def call_alleles(self, image, prediction: Prediction) -> Prediction:
+        called = self.translate_pixels_to_alleles(image._scaler[np.newaxis, :], prediction.image, image.data,
+                                                  image._panel)
+        if "called_alleles_manual" in image.meta:
+            # ground-truth annotations hold no DYS / AMEL markers (allele_callers.py:54-58)
+            called = [m for m in called if m.name not in NON_AUTOSOMAL_MARKERS]
+        prediction.meta["called_alleles"] = called
+        return prediction
+
+    def translate_pixels_to_alleles(self, scaler: np.ndarray, prediction_image: np.ndarray, image: np.ndarray,
+                                    panel: Panel) -> List[Marker]:
+        scaler = np.asarray(scaler)
+        bp_of_col = scaler.reshape(-1)
+        loci: Dict[Tuple[int, str], Dict[str, None]] = {}
+        rfus: Dict[Tuple[str, str], int] = {}
+        for dye, dye_pred in enumerate(prediction_image):
+            positive = np.asarray(dye_pred)[:, 0] >= 0.5
+            if not positive.any():
+                LOGGER.warning(f"No predictions present in dye row {dye}")
+                continue
+            edges = np.diff(np.concatenate(([0], positive.view(np.int8), [0])))
+            starts, stops = np.flatnonzero(edges == 1), np.flatnonzero(edges == -1)
+            table = self._table(panel, dye)
+            rfu_row = np.asarray(image)[dye, :, 0]
+            for a, b in zip(starts, stops):
+                mean_bp = np.mean(bp_of_col[a:b])
+                marker_name, allele_name = table.nearest(float(mean_bp))
+                loci.setdefault((dye, marker_name), {})[allele_name] = None
+                key = (marker_name, allele_name)
+                rfus[key] = int(max(rfus.get(key, 0), rfu_row[a:b].max()))
+        return [Marker(dye, marker_name, alleles=[Allele(name=a, height=rfus[(marker_name, a)]) for a in alleles])
+                for (dye, marker_name), alleles in loci.items()]

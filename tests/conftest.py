@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("g_"))
 
 
 def load_golden(name):
