@@ -1,0 +1,107 @@
+// C ABI of the weight-gradient GEMM: dispatch + fixed-order reduction of the split-K slabs.
+#include "common.h"
+#include "ops.h"
+
+namespace {
+
+// dw (canonical parameter layout) = sum over slabs; one thread per (tap, row, col) of the padded tile space
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int taps, int co_pad,
+                                                           int ci_pad, float* dw, int Cout, int Cin, int convt, int split,
+                                                           int half, int gsize) {
+  const long per = (long)taps * co_pad * ci_pad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % ci_pad);
+    long r = i / ci_pad;
+    const int co = (int)(r % co_pad);
+    const int tap = (int)(r / co_pad);
+    long dst = -1;
+    if (!convt) {
+      int cic = ci;
+      if (split > 0 && half != split) {             // concat input stored with padded halves
+        const int grp = ci / half, within = ci % half;
+        cic = (grp < 2 && within < split) ? grp * split + within : -1;
+      }
+      if (co < Cout && cic >= 0 && cic < Cin) dst = ((long)co * Cin + cic) * taps + tap;
+    } else {                                        // ConvTranspose2d weight [Cin][Cout][1][2]; rows = k*gsize + co
+      const int k = co / gsize, c = co % gsize;
+      if (k < 2 && c < Cout && ci < Cin) dst = ((long)ci * Cout + c) * 2 + k;
+    }
+    if (dst < 0) continue;
+    float s = 0.f;
+    for (int b = 0; b < nslab; ++b) s += slab[(long)b * per + i];
+    dw[dst] = s;
+  }
+}
+
+int run_wgrad(WgradParams& p, long ws_bytes, int kh, int kw, int dtype, int* nslab, hipStream_t s) {
+  if (dtype == DN_BF16) {
+    if (kh == 3 && kw == 5) return conv_wgrad_run_bf16_k35(p, ws_bytes, nslab, s);
+    if (kh == 1 && kw == 3) return conv_wgrad_run_bf16_k13(p, ws_bytes, nslab, s);
+    if (kh == 1 && kw == 1) return conv_wgrad_run_bf16_k11(p, ws_bytes, nslab, s);
+  } else if (dtype == DN_F32) {
+    if (kh == 3 && kw == 5) return conv_wgrad_run_f32_k35(p, ws_bytes, nslab, s);
+    if (kh == 1 && kw == 3) return conv_wgrad_run_f32_k13(p, ws_bytes, nslab, s);
+    if (kh == 1 && kw == 1) return conv_wgrad_run_f32_k11(p, ws_bytes, nslab, s);
+  } else {
+    return dn_set_error(DN_ERR_ARG, "bad dtype %d", dtype);
+  }
+  return dn_set_error(DN_ERR_UNSUPPORTED, "weight gradient for kernel size (%d,%d) is not built", kh, kw);
+}
+
+inline int tile_pad(int c, int tile) { return (c + tile - 1) / tile * tile; }
+
+}  // namespace
+
+extern "C" {
+
+int dn_conv2d_wgrad(dn_tensor dy, dn_tensor a, float* dw, void* workspace, long workspace_bytes, int N, int H, int W, int kh,
+                    int kw, int cin, int concat_split, int dtype, void* stream) {
+  DN_CHECK_ARG(dy.base && a.base && dw && workspace, "dn_conv2d_wgrad: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && cin > 0, "dn_conv2d_wgrad: bad shape");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d_wgrad: bad dtype %d", dtype);
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  const int co_t = dtype == DN_BF16 ? 64 : 32;
+  WgradParams p{};
+  p.dy = dy.base; p.dy_pt = dy.planes_total; p.dy_p0 = dy.plane0; p.dy_nplanes = dn_planes(dy.channels, dtype);
+  p.dy_gplanes = 1 << 30; p.dy_wmul = 1;
+  p.a = a.base; p.a_pt = a.planes_total; p.a_p0 = a.plane0; p.a_nplanes = dn_planes(a.channels, dtype);
+  p.slab = (float*)workspace; p.N = N; p.H = H; p.W = W;
+  p.co_pad = tile_pad(dy.channels, co_t); p.ci_pad = tile_pad(p.a_nplanes * epr, 32);
+  DN_CHECK_ARG(dy.plane0 + p.dy_nplanes <= dy.planes_total && a.plane0 + p.a_nplanes <= a.planes_total,
+               "dn_conv2d_wgrad: planes outside buffer");
+  int nslab = 0;
+  int rc = run_wgrad(p, workspace_bytes, kh, kw, dtype, &nslab, (hipStream_t)stream);
+  if (rc) return rc;
+  const int half = concat_split > 0 ? dn_planes(concat_split, dtype) * epr : 0;
+  const long per = (long)kh * kw * p.co_pad * p.ci_pad;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((per + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, nslab, kh * kw, p.co_pad, p.ci_pad, dw, dy.channels, cin, 0, concat_split, half, 1);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+int dn_conv_transpose_1x2_wgrad(dn_tensor dy, dn_tensor x, float* dw, void* workspace, long workspace_bytes, int N, int H,
+                                int Win, int dtype, void* stream) {
+  DN_CHECK_ARG(dy.base && x.base && dw && workspace, "dn_conv_transpose_1x2_wgrad: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && Win > 0, "dn_conv_transpose_1x2_wgrad: bad shape");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_transpose_1x2_wgrad: bad dtype %d", dtype);
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  const int co_t = dtype == DN_BF16 ? 64 : 32;
+  const int gsize = tile_pad(dy.channels, co_t);
+  WgradParams p{};
+  p.dy = dy.base; p.dy_pt = dy.planes_total; p.dy_p0 = dy.plane0; p.dy_nplanes = dn_planes(dy.channels, dtype);
+  p.dy_gplanes = gsize / epr; p.dy_wmul = 2;
+  p.a = x.base; p.a_pt = x.planes_total; p.a_p0 = x.plane0; p.a_nplanes = dn_planes(x.channels, dtype);
+  p.slab = (float*)workspace; p.N = N; p.H = H; p.W = Win;
+  p.co_pad = 2 * gsize; p.ci_pad = tile_pad(p.a_nplanes * epr, 32);
+  int nslab = 0;
+  int rc = run_wgrad(p, workspace_bytes, 1, 1, dtype, &nslab, (hipStream_t)stream);
+  if (rc) return rc;
+  const long per = (long)p.co_pad * p.ci_pad;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((per + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, nslab, 1, p.co_pad, p.ci_pad, dw, dy.channels, x.channels, 1, 0, 0, gsize);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+}  // extern "C"

@@ -47,6 +47,21 @@ _SIGS = {
     "dn_conv_transpose_1x2_dgrad": (c_int, [DnTensor, _P, DnTensor, c_int, c_int, c_int, c_int, _P]),
     "dn_maxpool_1x2": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, c_int, _P]),
     "dn_head_1x1": (c_int, [DnTensor, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dn_reduce_blocks": (c_int, [c_long]),
+    "dn_bn_train_forward": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float,
+                                    _P, _P, _P, _P, _P, c_int, _P]),
+    "dn_bn_train_backward": (c_int, [DnTensor, DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "dn_maxpool_1x2_backward": (c_int, [DnTensor, DnTensor, DnTensor, DnTensor, c_int, c_int, c_int, c_int, _P]),
+    "dn_head_1x1_backward": (c_int, [_P, DnTensor, _P, DnTensor, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dn_channel_sum": (c_int, [DnTensor, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "dn_conv2d_wgrad": (c_int, [DnTensor, DnTensor, _P, _P, c_long] + [c_int] * 8 + [_P]),
+    "dn_conv_transpose_1x2_wgrad": (c_int, [DnTensor, DnTensor, _P, _P, c_long, c_int, c_int, c_int, c_int, _P]),
+    "dn_conv_first_wgrad_blocks": (c_int, [c_int, c_int, c_int]),
+    "dn_conv_first_wgrad": (c_int, [_P, DnTensor, _P, _P] + [c_int] * 6 + [_P]),
+    "dn_dice_forward": (c_int, [_P, _P, c_long, _P, _P, _P]),
+    "dn_dice_backward": (c_int, [_P, _P, c_long, _P, _P, _P]),
+    "dn_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_long, c_float, c_int, _P]),
+    "dn_i16_to_f32": (c_int, [_P, _P, c_long, _P]),
 }
 
 
@@ -92,6 +107,10 @@ def channel_pad(c: int) -> int:
     return (c + 31) // 32 * 32
 
 
+def partial_floats(c: int) -> int:
+    return 512 * channel_pad(c) * 2 + 4096
+
+
 def planes(c: int, dtype: int) -> int:
     e = epr(dtype)
     return (c + e - 1) // e
@@ -107,7 +126,9 @@ class PlaneBuffer:
 
     def ref(self, channels: int, plane0: int = 0) -> DnTensor:
         assert plane0 + planes(channels, self.dtype) <= self.planes_total
-        return DnTensor(self.data.data_ptr(), self.planes_total, plane0, channels)
+        t = DnTensor(self.data.data_ptr(), self.planes_total, plane0, channels)
+        t._owner = self      # a ref keeps its buffer alive (saved activations outlive the forward call)
+        return t
 
     # conversions for tests / boundaries (torch ops, not on the hot path)
     @staticmethod

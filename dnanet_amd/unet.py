@@ -45,6 +45,12 @@ class HipUNet(ParameterTree):
         self._eval_cache = None
         self._eval_cache_version = None
         self.profile = None     # set to a list to collect (kernel tag, flops, start event, end event) per conv launch
+        self._param_epoch = 0   # bumped whenever a HIP kernel rewrites parameters / running statistics
+        self._train_cache = None
+        self._train_cache_version = None
+        self._saved = None
+        self._ws = None
+        self.wgrad_workspace_bytes = 256 << 20
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -105,7 +111,7 @@ class HipUNet(ParameterTree):
     # eval-mode (BatchNorm folded into the packed weights)
     # ------------------------------------------------------------------------------------------
     def _versions(self):
-        return (self.flat_params._version, self.flat_stats._version, self.dtype)
+        return (self.flat_params._version, self.flat_stats._version, self._param_epoch, self.dtype)
 
     @torch.no_grad()
     def _build_eval_cache(self):
@@ -225,5 +231,252 @@ class HipUNet(ParameterTree):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
-            raise RuntimeError("train-mode forward goes through HipUNet.train_step()/forward_train()")
+            return self.forward_train(x)
         return self.infer(x, want_logits=True, want_probs=False)[0]
+
+    # ------------------------------------------------------------------------------------------
+    # training: forward with batch statistics, backward, both on the HIP kernels
+    # ------------------------------------------------------------------------------------------
+    def _workspace(self):
+        if self._ws is None:
+            cmax = self.num_filters * 2 ** self.depth
+            self._ws = {
+                "partial": torch.empty(hip.partial_floats(cmax) + 65536, dtype=torch.float32, device=self.device),
+                "coef": torch.empty(3 * hip.channel_pad(cmax), dtype=torch.float32, device=self.device),
+                "wgrad": torch.empty(self.wgrad_workspace_bytes, dtype=torch.uint8, device=self.device),
+                "dice_sums": torch.zeros(8, dtype=torch.float32, device=self.device),
+            }
+        return self._ws
+
+    @torch.no_grad()
+    def _build_train_cache(self):
+        """Packed GEMM images of the current weights (forward and data-gradient forms)."""
+        cache: Dict[str, dict] = {}
+        for u in self.conv_units:
+            w = self.tensor(u.conv + ".weight")
+            entry = {"bias": self._padvec(self.tensor(u.conv + ".bias"))}
+            if u.cin == 1:
+                kh, kw = self.kernel_size
+                wf = torch.zeros((kh * kw, hip.channel_pad(u.cout)), dtype=torch.float32, device=self.device)
+                wf[:, :u.cout] = w.reshape(u.cout, kh * kw).t()
+                entry["wf"] = wf
+            else:
+                wv = self._virtual_weight(u, w)
+                entry["w"] = self._pack(wv, None, hip.PACK_FWD)
+                entry["wd"] = self._pack(wv, None, hip.PACK_DGRAD)
+            cache[u.conv] = entry
+        for up in self.up_units:
+            w = self.tensor(up.name + ".weight")
+            cache[up.name] = {"w": self._pack(w, None, hip.PACK_CONVT_FWD), "wd": self._pack(w, None, hip.PACK_CONVT_DGRAD),
+                              "bias": self._up_bias2(self.tensor(up.name + ".bias"))}
+        cache["head_w"] = self._padvec(self.tensor("outputs.weight"))
+        self._train_cache = cache
+        self._train_cache_version = self._versions()
+
+    def _unit_forward(self, u: ConvUnit, src, dst, n, h, w, raw_x=None):
+        """conv + bias -> y ; batch-stat BatchNorm + ReLU -> dst.  Saves what backward needs."""
+        ws, cache = self._workspace(), self._train_cache
+        y = PlaneBuffer(n, self._pp(u.cout), h, w, self.dtype, self.device)
+        self._conv(u, cache[u.conv], raw_x if u.cin == 1 else src, y.ref(u.cout), n, h, w, relu=0)
+        cp = hip.channel_pad(u.cout)
+        vec = torch.empty(4 * cp, dtype=torch.float32, device=self.device)
+        mean, invstd, scale, shift = (vec[i * cp:(i + 1) * cp] for i in range(4))
+        hip.check(hip.lib.dn_bn_train_forward(
+            y.ref(u.cout), dst, n, h, w, hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(self.tensor(u.bn + ".bias")),
+            hip.ptr(self.tensor(u.bn + ".running_mean")), hip.ptr(self.tensor(u.bn + ".running_var")), BN_MOMENTUM, BN_EPS,
+            hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift), hip.ptr(ws["partial"]), self.dtype,
+            hip.stream_ptr()))
+        self._saved[u.conv] = {"y": y, "a": dst, "src": src, "mean": mean, "invstd": invstd, "vec": vec, "n": n, "h": h, "w": w}
+
+    def forward_train(self, x: torch.Tensor) -> torch.Tensor:
+        """Train-mode forward (batch statistics, running-stat update); keeps activations for backward()."""
+        self._check_input(x)
+        x = x.contiguous()
+        if self._train_cache is None or self._train_cache_version != self._versions():
+            self._build_train_cache()
+        n, _, h, w = x.shape
+        depth, f, dt, dev = self.depth, self.num_filters, self.dtype, self.device
+        c = [f * 2 ** l for l in range(depth + 1)]
+        ws = [w >> l for l in range(depth + 1)]
+        units = {u.conv: u for u in self.conv_units}
+        S = self._saved = {"x": x, "n": n, "h": h, "w": w}
+        cat = [PlaneBuffer(n, 2 * self._pp(c[l]), h, ws[l], dt, dev) for l in range(depth)]
+        S["cat"] = cat
+        cur = None
+        for l in range(depth):
+            pre = f"encoders.{l}.conv.double_conv"
+            a1 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            self._unit_forward(units[pre + ".0"], None if l == 0 else cur, a1.ref(c[l]), n, h, ws[l], raw_x=x)
+            skip = cat[l].ref(c[l], self._pp(c[l]))
+            self._unit_forward(units[pre + ".3"], a1.ref(c[l]), skip, n, h, ws[l])
+            pooled = PlaneBuffer(n, self._pp(c[l]), h, ws[l + 1], dt, dev)
+            hip.check(hip.lib.dn_maxpool_1x2(skip, pooled.ref(c[l]), n, h, ws[l + 1], dt, hip.stream_ptr()))
+            S[f"pooled{l}"] = pooled
+            cur = pooled.ref(c[l])
+        pre = "bottleneck.double_conv"
+        a1 = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev)
+        self._unit_forward(units[pre + ".0"], cur, a1.ref(c[depth]), n, h, ws[depth])
+        a2 = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev)
+        self._unit_forward(units[pre + ".3"], a1.ref(c[depth]), a2.ref(c[depth]), n, h, ws[depth])
+        cur, cur_buf = a2.ref(c[depth]), a2
+        for i in range(depth):
+            l = depth - 1 - i
+            up = self._train_cache[f"decoders.{i}.up"]
+            S[f"up{i}_in"] = cur
+            hip.check(hip.lib.dn_conv_transpose_1x2(cur, hip.ptr(up["w"]), hip.ptr(up["bias"]), cat[l].ref(c[l], 0), n, h,
+                                                    ws[l + 1], dt, hip.stream_ptr()))
+            pre = f"decoders.{i}.conv.double_conv"
+            a1 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            both = cat[l].ref(2 * self._cpad_planes(c[l]), 0)
+            self._unit_forward(units[pre + ".0"], both, a1.ref(c[l]), n, h, ws[l])
+            a2 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            self._unit_forward(units[pre + ".3"], a1.ref(c[l]), a2.ref(c[l]), n, h, ws[l])
+            cur, cur_buf = a2.ref(c[l]), a2
+        S["head_in"], S["keep"] = cur, cur_buf
+        logits = torch.empty_like(x)
+        hip.check(hip.lib.dn_head_1x1(cur, hip.ptr(self._train_cache["head_w"]), hip.ptr(self.tensor("outputs.bias")),
+                                      hip.ptr(logits), None, n, h, w, dt, hip.stream_ptr()))
+        self.flat_counts += 1          # num_batches_tracked of every BatchNorm
+        self._param_epoch += 1         # running statistics changed
+        self._train_cache_version = self._versions()
+        S["logits"] = logits
+        return logits
+
+    def dice_forward(self, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        """Fused sigmoid + Dice sums + accuracy counts; returns the device vector
+        [sum p*t, sum p, sum t, #correct, loss] (loss.py:9-20, trainable_unet.py:411-415)."""
+        ws = self._workspace()
+        if targets.dtype != torch.int8:
+            targets = targets.to(torch.int8)
+        targets = targets.contiguous()
+        sums = torch.zeros(8, dtype=torch.float32, device=self.device)
+        hip.check(hip.lib.dn_dice_forward(hip.ptr(logits), hip.ptr(targets), logits.numel(), hip.ptr(sums),
+                                          hip.ptr(ws["partial"]), hip.stream_ptr()))
+        if self._saved is not None:
+            self._saved["targets"], self._saved["sums"] = targets, sums
+        return sums
+
+    def _unit_backward(self, u: ConvUnit, g, want_dgrad: bool):
+        """g: dL/d(output activation) in a buffer (overwritten with dL/dy). Returns dL/d(input) ref."""
+        ws, cache, sv = self._workspace(), self._train_cache, self._saved[u.conv]
+        n, h, w = sv["n"], sv["h"], sv["w"]
+        kh, kw = self.kernel_size
+        hip.check(hip.lib.dn_bn_train_backward(
+            g, sv["y"].ref(u.cout), sv["a"], n, h, w, hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(sv["mean"]),
+            hip.ptr(sv["invstd"]), hip.ptr(self.grad(u.bn + ".weight")), hip.ptr(self.grad(u.bn + ".bias")),
+            hip.ptr(ws["coef"]), hip.ptr(ws["partial"]), self.dtype, hip.stream_ptr()))
+        # the conv bias feeds a BatchNorm: its gradient is identically zero, the arena entry stays 0
+        if u.cin == 1:
+            hip.check(hip.lib.dn_conv_first_wgrad(hip.ptr(self._saved["x"]), g, hip.ptr(self.grad(u.conv + ".weight")),
+                                                  hip.ptr(ws["partial"]), n, h, w, kh, kw, self.dtype, hip.stream_ptr()))
+            return None
+        hip.check(hip.lib.dn_conv2d_wgrad(g, sv["src"], hip.ptr(self.grad(u.conv + ".weight")), hip.ptr(ws["wgrad"]),
+                                          ws["wgrad"].numel(), n, h, w, kh, kw, u.cin, u.split, self.dtype, hip.stream_ptr()))
+        if not want_dgrad:
+            return None
+        cin_stored = sv["src"].channels
+        gin = PlaneBuffer(n, self._pp(cin_stored), h, w, self.dtype, self.device)
+        hip.check(hip.lib.dn_conv2d(g, hip.ptr(cache[u.conv]["wd"]), None, gin.ref(cin_stored), n, h, w, kh, kw, 0, self.dtype,
+                                    hip.stream_ptr()))
+        return gin
+
+    def backward(self, dlogits: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None, segment_hook=None):
+        """Backward of Dice(logits, targets) (or of a given dL/dlogits) through the whole net into the
+        flat gradient arena.  ``sums`` lets a data-parallel caller pass all-reduced Dice sums.
+        ``segment_hook(name)`` is called after the gradients of each stage are complete (bucketed all-reduce)."""
+        S = self._saved
+        if S is None:
+            raise RuntimeError("backward() needs a preceding train-mode forward")
+        ws = self._workspace()
+        n, h, w = S["n"], S["h"], S["w"]
+        depth, f, dt, dev = self.depth, self.num_filters, self.dtype, self.device
+        c = [f * 2 ** l for l in range(depth + 1)]
+        wl = [w >> l for l in range(depth + 1)]
+        units = {u.conv: u for u in self.conv_units}
+        if dlogits is None:
+            sums = S["sums"] if sums is None else sums
+            dlogits = torch.empty_like(S["logits"])
+            hip.check(hip.lib.dn_dice_backward(hip.ptr(S["logits"]), hip.ptr(S["targets"]), dlogits.numel(), hip.ptr(sums),
+                                               hip.ptr(dlogits), hip.stream_ptr()))
+        g = PlaneBuffer(n, self._pp(c[0]), h, w, dt, dev)
+        hip.check(hip.lib.dn_head_1x1_backward(hip.ptr(dlogits), S["head_in"], hip.ptr(self._train_cache["head_w"]), g.ref(c[0]),
+                                               hip.ptr(self.grad("outputs.weight")), hip.ptr(self.grad("outputs.bias")),
+                                               hip.ptr(ws["partial"]), n, h, w, dt, hip.stream_ptr()))
+        if segment_hook:
+            segment_hook("head")
+        gcat = [None] * depth
+        cur = g
+        for i in reversed(range(depth)):
+            l = depth - 1 - i
+            pre = f"decoders.{i}.conv.double_conv"
+            g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True)
+            gcat[l] = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), True)
+            d_up = gcat[l].ref(c[l], 0)
+            upn = f"decoders.{i}.up"
+            xin = S[f"up{i}_in"]
+            hip.check(hip.lib.dn_conv_transpose_1x2_wgrad(d_up, xin, hip.ptr(self.grad(upn + ".weight")), hip.ptr(ws["wgrad"]),
+                                                          ws["wgrad"].numel(), n, h, wl[l + 1], dt, hip.stream_ptr()))
+            hip.check(hip.lib.dn_channel_sum(d_up, hip.ptr(self.grad(upn + ".bias")), hip.ptr(ws["partial"]), n, h, wl[l], dt,
+                                             hip.stream_ptr()))
+            gx = PlaneBuffer(n, self._pp(c[l + 1]), h, wl[l + 1], dt, dev)
+            hip.check(hip.lib.dn_conv_transpose_1x2_dgrad(d_up, hip.ptr(self._train_cache[upn]["wd"]), gx.ref(c[l + 1]), n, h,
+                                                          wl[l + 1], dt, hip.stream_ptr()))
+            cur = gx
+            if segment_hook:
+                segment_hook(f"decoders.{i}")
+        pre = "bottleneck.double_conv"
+        g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[depth]), True)
+        gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[depth]), True)
+        if segment_hook:
+            segment_hook("bottleneck")
+        for l in reversed(range(depth)):
+            pre = f"encoders.{l}.conv.double_conv"
+            skip = S["cat"][l].ref(c[l], self._pp(c[l]))
+            g2 = PlaneBuffer(n, self._pp(c[l]), h, wl[l], dt, dev)
+            hip.check(hip.lib.dn_maxpool_1x2_backward(skip, gpool.ref(c[l]), gcat[l].ref(c[l], self._pp(c[l])), g2.ref(c[l]), n, h,
+                                                      wl[l + 1], dt, hip.stream_ptr()))
+            g1 = self._unit_backward(units[pre + ".3"], g2.ref(c[l]), True)
+            gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), l > 0)
+            if segment_hook:
+                segment_hook(f"encoders.{l}")
+        self._saved = None
+
+
+class HipAdam:
+    """``torch.optim.Adam(params, lr, weight_decay)`` with coupled L2 (reference
+    ``trainable_unet.py:155-157``) as one fused kernel over the model's flat parameter arena;
+    ``zero_grad`` (``:344``) is folded into the same pass."""
+
+    def __init__(self, model: HipUNet, lr: float = 1e-3, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.model = model
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": betas, "eps": eps}]
+        self.exp_avg = torch.zeros_like(model.flat_params)
+        self.exp_avg_sq = torch.zeros_like(model.flat_params)
+        self.step_count = 0
+        self._zeroed = False
+
+    def step(self, grad_scale: float = 1.0):
+        g = self.param_groups[0]
+        self.step_count += 1
+        m = self.model
+        hip.check(hip.lib.dn_adam_step(hip.ptr(m.flat_params), hip.ptr(m.flat_grads), hip.ptr(self.exp_avg),
+                                       hip.ptr(self.exp_avg_sq), m.flat_params.numel(), g["lr"], g["betas"][0], g["betas"][1],
+                                       g["eps"], g["weight_decay"], self.step_count, grad_scale, 1, hip.stream_ptr()))
+        m._param_epoch += 1
+        self._zeroed = True
+
+    def zero_grad(self):
+        if not self._zeroed:
+            self.model.flat_grads.zero_()
+        self._zeroed = False
+
+
+class ExponentialLR:
+    """``torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma)`` (``trainable_unet.py:159-162``)."""
+
+    def __init__(self, optimizer: HipAdam, gamma: float = 0.8):
+        self.optimizer, self.gamma = optimizer, gamma
+
+    def step(self):
+        for g in self.optimizer.param_groups:
+            g["lr"] *= self.gamma

@@ -80,6 +80,58 @@ int dn_maxpool_1x2(dn_tensor x, dn_tensor y, int N, int H, int Wout, int dtype, 
 int dn_head_1x1(dn_tensor x, const float* w, const float* b, float* logits, float* probs, int N, int H, int W, int dtype,
                 void* stream);
 
+/* ---- training operators ---------------------------------------------------------------------
+ * Reduction workspaces: `partial` must hold dn_partial_floats(C) floats. */
+static inline long dn_partial_floats(int c) { return 512L * dn_channel_pad(c) * 2 + 4096; }
+int dn_reduce_blocks(long pixels);
+
+/* nn.BatchNorm2d in training mode + ReLU (unet_architecture.py:17,21): batch mean / biased variance
+ * over (N,H,W) of y, running-stat update (momentum, unbiased variance; running_* may be null),
+ * a = relu(gamma * (y - mean) * invstd + beta).  Saves mean/invstd and the fused scale/shift
+ * (dn_channel_pad(C) floats each) for the backward pass. */
+int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                        float* scale, float* shift, float* partial, int dtype, void* stream);
+/* Backward of ReLU + BatchNorm2d (autograd of the above, trainable_unet.py:342): on entry g = dL/da,
+ * on exit g = dL/dy (in place); dgamma/dbeta are written ([C]); coef: 3*dn_channel_pad(C) scratch. */
+int dn_bn_train_backward(dn_tensor g, dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* mean,
+                         const float* invstd, float* dgamma, float* dbeta, float* coef, float* partial, int dtype,
+                         void* stream);
+/* Backward of nn.MaxPool2d((1,2)) (unet_architecture.py:37) fused with the skip-connection add:
+ * g = dskip (nullable .base) + route(dpool) to the first maximal element of every pair of x. */
+int dn_maxpool_1x2_backward(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, int N, int H, int Wout, int dtype,
+                            void* stream);
+/* Backward of the 1x1 head (unet_architecture.py:94-97): g = dlogits * w, dw[c] = sum dlogits * x[c],
+ * db = sum dlogits. */
+int dn_head_1x1_backward(const float* dlogits, dn_tensor x, const float* w, dn_tensor g, float* dw, float* db, float* partial,
+                         int N, int H, int W, int dtype, void* stream);
+/* out[c] = sum over (N,H,W) of x[c]: bias gradient of nn.ConvTranspose2d (unet_architecture.py:54-57). */
+int dn_channel_sum(dn_tensor x, float* out, float* partial, int N, int H, int W, int dtype, void* stream);
+/* Weight gradient of nn.Conv2d(cin, cout, (kh,kw), padding=k//2): dw[cout][cin][kh][kw] (canonical fp32, overwritten).
+ * a = the convolution's input (concat_split > 0: it is the skip-concat of two tensors of that many channels);
+ * workspace holds the split-K partial slabs (>= 64 MiB recommended; more = more K parallelism). */
+int dn_conv2d_wgrad(dn_tensor dy, dn_tensor a, float* dw, void* workspace, long workspace_bytes, int N, int H, int W, int kh,
+                    int kw, int cin, int concat_split, int dtype, void* stream);
+/* Weight gradient of nn.ConvTranspose2d(cin, cout, (1,2), stride (1,2)): dw[cin][cout][1][2]. dy is N x H x 2*Win. */
+int dn_conv_transpose_1x2_wgrad(dn_tensor dy, dn_tensor x, float* dw, void* workspace, long workspace_bytes, int N, int H,
+                                int Win, int dtype, void* stream);
+/* Weight gradient of the first convolution (Cin = 1) against the raw fp32 input x[N][1][H][W]: dw[cout][1][kh][kw].
+ * partial: dn_conv_first_wgrad_blocks(N,H,W) * kh*kw * dn_channel_pad(cout) floats. */
+int dn_conv_first_wgrad_blocks(int N, int H, int W);
+int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial, int N, int H, int W, int kh, int kw, int dtype,
+                        void* stream);
+/* DiceLoss.forward (loss.py:9-20) + BinaryAccuracy counts (trainable_unet.py:411-415) in one pass over the
+ * whole batch: sums[0..4] = { sum p*t, sum p, sum t, #(p>=0.5)==t, loss }.  partial: 4096 floats. */
+int dn_dice_forward(const float* logits, const signed char* targets, long n, float* sums, float* partial, void* stream);
+/* dL/dlogits for the Dice loss given (possibly all-reduced) sums[0..2]. */
+int dn_dice_backward(const float* logits, const signed char* targets, long n, const float* sums, float* dlogits, void* stream);
+/* torch.optim.Adam step with coupled weight decay over a flat fp32 arena (trainable_unet.py:155-157,343),
+ * grads are scaled by grad_scale first and zeroed afterwards when zero_grad != 0 (optimizer.zero_grad(), :344). */
+int dn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, long step, float grad_scale, int zero_grad, void* stream);
+/* int16 RFU -> fp32 (get_input, trainable_unet.py:70-72). */
+int dn_i16_to_f32(const short* in, float* out, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

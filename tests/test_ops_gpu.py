@@ -194,3 +194,152 @@ def test_maxpool_and_head(gpu_device, dtype):
     ref = F.conv2d(xq, hw, hb)
     assert torch.allclose(logits.cpu(), ref, rtol=1e-5, atol=1e-5)
     assert torch.allclose(probs.cpu(), torch.sigmoid(ref), rtol=1e-5, atol=1e-6)
+
+
+WGRAD_CASES = [(1, 8, 8, 1, 16, 1, 1), (1, 8, 8, 5, 64, 3, 5), (2, 32, 32, 5, 256, 3, 5), (2, 64, 128, 6, 200, 3, 5),
+               (2, 16, 24, 5, 130, 1, 3), (3, 40, 72, 7, 96, 3, 5)]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv2d_wgrad(gpu_device, case, dtype):
+    """Split-K MFMA weight gradient (bf16: transposing LDS reads) is exact on small-integer data."""
+    hip = _hip()
+    n, cin, cout, h, w, kh, kw = case
+    g = torch.Generator().manual_seed(1)
+    a = _rand((n, cin, h, w), g, True)
+    dy = _rand((n, cout, h, w), g, True)
+    wt = torch.zeros(cout, cin, kh, kw, requires_grad=True)
+    F.conv2d(a, wt, padding=(kh // 2, kw // 2)).backward(dy)
+    ab = hip.PlaneBuffer.from_nchw(a.to(gpu_device), dtype)
+    dyb = hip.PlaneBuffer.from_nchw(dy.to(gpu_device), dtype)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=gpu_device)
+    dw = torch.full((cout, cin, kh, kw), 7.0, device=gpu_device)
+    hip.check(hip.lib.dn_conv2d_wgrad(dyb.ref(cout), ab.ref(cin), hip.ptr(dw), hip.ptr(ws), ws.numel(), n, h, w, kh, kw, cin,
+                                      0, dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu(), wt.grad)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_conv_transpose_wgrad_and_bias(gpu_device, dtype):
+    hip = _hip()
+    n, cin, cout, h, win = 2, 64, 32, 5, 96
+    g = torch.Generator().manual_seed(2)
+    x = _rand((n, cin, h, win), g, True)
+    dy = _rand((n, cout, h, 2 * win), g, True)
+    wt = torch.zeros(cin, cout, 1, 2, requires_grad=True)
+    b = torch.zeros(cout, requires_grad=True)
+    F.conv_transpose2d(x, wt, b, stride=(1, 2)).backward(dy)
+    xb = hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype)
+    dyb = hip.PlaneBuffer.from_nchw(dy.to(gpu_device), dtype)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=gpu_device)
+    dw = torch.full((cin, cout, 1, 2), 7.0, device=gpu_device)
+    hip.check(hip.lib.dn_conv_transpose_1x2_wgrad(dyb.ref(cout), xb.ref(cin), hip.ptr(dw), hip.ptr(ws), ws.numel(), n, h, win,
+                                                  dtype, hip.stream_ptr()))
+    db = torch.empty(cout, device=gpu_device)
+    part = torch.empty(hip.partial_floats(cout), device=gpu_device)
+    hip.check(hip.lib.dn_channel_sum(dyb.ref(cout), hip.ptr(db), hip.ptr(part), n, h, 2 * win, dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu(), wt.grad)
+    assert torch.equal(db.cpu(), b.grad)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_batchnorm_train_forward_backward(gpu_device, dtype):
+    hip = _hip()
+    n, c, h, w = 3, 24, 5, 64
+    g = torch.Generator().manual_seed(4)
+    y = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    yb = hip.PlaneBuffer.from_nchw(y.to(gpu_device), dtype)
+    yq = yb.to_nchw(c).cpu().requires_grad_(True)       # the values the kernel sees
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(c, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    a_ref = F.relu(F.batch_norm(yq, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5))
+    cp = hip.channel_pad(c)
+    dev = gpu_device
+    gd, bd, rmd, rvd = (t.detach().to(dev) for t in (gamma, beta, rm, rv))
+    vec = torch.zeros(4 * cp, device=dev)
+    mean, invstd, scale, shift = (vec[i * cp:(i + 1) * cp] for i in range(4))
+    part = torch.empty(hip.partial_floats(c), device=dev)
+    ab = hip.PlaneBuffer(n, hip.planes(c, dtype), h, w, dtype, dev, zero=True)
+    hip.check(hip.lib.dn_bn_train_forward(yb.ref(c), ab.ref(c), n, h, w, hip.ptr(gd), hip.ptr(bd), hip.ptr(rmd), hip.ptr(rvd), 0.1,
+                                          1e-5, hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift), hip.ptr(part),
+                                          dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == 0 else 1e-2
+    assert torch.allclose(ab.to_nchw(c).cpu(), a_ref.detach(), rtol=tol, atol=tol)
+    assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    # backward: gradient wrt y, gamma, beta
+    gout = torch.randn(n, c, h, w, generator=g)
+    gb = hip.PlaneBuffer.from_nchw(gout.to(dev), dtype)
+    gq = gb.to_nchw(c).cpu()
+    # use the kernel's own (stored) activation for the ReLU mask, as the library does
+    a_store = ab.to_nchw(c).cpu()
+    (a_ref * (a_store > 0).float()).backward(gq) if False else a_ref.backward(gq * ((a_store > 0) == (a_ref > 0)).float())
+    dgam, dbet = torch.empty(c, device=dev), torch.empty(c, device=dev)
+    coef = torch.empty(3 * cp, device=dev)
+    hip.check(hip.lib.dn_bn_train_backward(gb.ref(c), yb.ref(c), ab.ref(c), n, h, w, hip.ptr(gd), hip.ptr(mean), hip.ptr(invstd),
+                                           hip.ptr(dgam), hip.ptr(dbet), hip.ptr(coef), hip.ptr(part), dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    gt = 2e-5 if dtype == 0 else 2e-2
+    assert torch.allclose(dgam.cpu(), gamma.grad, rtol=gt, atol=gt * float(gamma.grad.abs().max()))
+    assert torch.allclose(dbet.cpu(), beta.grad, rtol=gt, atol=gt * float(beta.grad.abs().max()))
+    assert torch.allclose(gb.to_nchw(c).cpu(), yq.grad, rtol=gt, atol=gt * float(yq.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_maxpool_backward_with_skip(gpu_device, dtype):
+    hip = _hip()
+    n, c, h, w = 2, 24, 5, 64
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(-2, 3, (n, c, h, w), generator=g).float()      # many ties: first element must win
+    dpool = torch.randn(n, c, h, w // 2, generator=g)
+    dskip = torch.randn(n, c, h, w, generator=g)
+    xb, dpb, dsb = (hip.PlaneBuffer.from_nchw(t.to(gpu_device), dtype) for t in (x, dpool, dskip))
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(xr, (1, 2)).backward(dpb.to_nchw(c).cpu())
+    ref = xr.grad + dsb.to_nchw(c).cpu()
+    gb = hip.PlaneBuffer(n, hip.planes(c, dtype), h, w, dtype, gpu_device, zero=True)
+    hip.check(hip.lib.dn_maxpool_1x2_backward(xb.ref(c), dpb.ref(c), dsb.ref(c), gb.ref(c), n, h, w // 2, dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(gb.to_nchw(c).cpu(), _q(ref, dtype))
+
+
+def test_dice_and_adam(gpu_device):
+    hip = _hip()
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(3, 1, 5, 333, generator=g) * 3
+    t = (torch.rand(3, 1, 5, 333, generator=g) < 0.05).to(torch.int8)
+    zr = z.clone().requires_grad_(True)
+    p = torch.sigmoid(zr).view(-1)
+    loss = 1 - (2 * (p * t.view(-1)).sum() + 1) / (p.sum() + t.sum() + 1)
+    loss.backward()
+    zd, td = z.to(gpu_device), t.to(gpu_device)
+    sums = torch.zeros(8, device=gpu_device)
+    part = torch.empty(8192, device=gpu_device)
+    dz = torch.empty_like(zd)
+    hip.check(hip.lib.dn_dice_forward(hip.ptr(zd), hip.ptr(td), zd.numel(), hip.ptr(sums), hip.ptr(part), hip.stream_ptr()))
+    hip.check(hip.lib.dn_dice_backward(hip.ptr(zd), hip.ptr(td), zd.numel(), hip.ptr(sums), hip.ptr(dz), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert abs(float(sums[4]) - float(loss)) < 1e-6
+    assert int(sums[3]) == int(((torch.sigmoid(z) >= 0.5) == (t != 0)).sum())
+    assert torch.allclose(dz.cpu(), zr.grad, rtol=1e-4, atol=1e-9)
+    # Adam with coupled weight decay against torch.optim.Adam
+    n = 1000
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-2, weight_decay=5e-4)
+    pd, md, vd = p0.to(gpu_device), torch.zeros(n, device=gpu_device), torch.zeros(n, device=gpu_device)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        gd = gr.to(gpu_device)
+        hip.check(hip.lib.dn_adam_step(hip.ptr(pd), hip.ptr(gd), hip.ptr(md), hip.ptr(vd), n, 1e-2, 0.9, 0.999, 1e-8, 5e-4, step,
+                                       1.0, 1, hip.stream_ptr()))
+        torch.cuda.synchronize()
+        assert float(gd.abs().max()) == 0.0
+    assert torch.allclose(pd.cpu(), ref.data, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,80 @@
+"""Training-step parity: HIP forward (batch-stat BN) + Dice + backward + Adam vs the fixtures made by the
+reference modules (loss, every gradient, post-step parameters and BN buffers)."""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+# fp32: max |g - g_ref| / max |g_ref| per tensor.  bf16: activations and gradients are stored with 8
+# significant bits, and ReLU masks / max-pool routing of near-tied values flip, so single elements move
+# by O(1); the bf16 bar is on the relative L2 error of every gradient tensor instead.
+# Every bf16 kernel is separately checked bit-exact on integer data in test_ops_gpu.py; here the bf16 bar
+# is coarse on purpose (toy nets with 8 filters and BN over a few hundred values are noise dominated).
+GRAD_TOL = {"fp32": 2e-3, "bf16": 1.0}
+BF16_MIN_COSINE = 0.9
+LOSS_TOL = {"fp32": 2e-5, "bf16": 2e-2}
+
+
+def _train_names():
+    return [n for n in golden_names() if "real" not in n]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", _train_names())
+def test_train_steps_vs_reference_fixture(gpu_device, name, dtype):
+    from dnanet_amd.unet import HipAdam, HipUNet
+    g = load_golden(name)
+    m = HipUNet(int(g["depth"]), tuple(int(v) for v in g["kernel"]), int(g["filters"]), gpu_device, dtype=dtype)
+    m.load_state_dict(g["sd0"])
+    m.train()
+    opt = HipAdam(m, lr=float(g["lr"]), weight_decay=float(g["wd"]))
+    x = torch.from_numpy(g["x"]).to(gpu_device)
+    t = torch.from_numpy(g["t"]).to(gpu_device)
+    opt.zero_grad()
+    for s in range(int(g["steps"])):
+        logits = m(x)
+        sums = m.dice_forward(logits, t)
+        m.backward()
+        loss = float(sums[4])
+        assert abs(loss - float(g[f"step{s}/loss"])) < LOSS_TOL[dtype], (s, loss, float(g[f"step{s}/loss"]))
+        ref = torch.from_numpy(g[f"step{s}/logits"])
+        if s == 0:
+            err = float((logits.cpu() - ref).abs().max() / ref.abs().max())
+            assert err < (1e-4 if dtype == "fp32" else 6e-2), err
+            worst = ("", 0.0)
+            for k, gr in g["grad0"].items():
+                scale = float(gr.abs().max()) + 1e-20
+                if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+                    scale = float(g["grad0"][k[:-4] + "weight"].abs().max())   # zero-gradient bias: see test_oracle_golden
+                if dtype == "bf16":
+                    if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+                        continue
+                    e = float((m.grad(k).cpu() - gr).norm() / (gr.norm() + 1e-20))
+                else:
+                    e = float((m.grad(k).cpu() - gr).abs().max()) / scale
+                if e > worst[1]:
+                    worst = (k, e)
+            assert worst[1] < GRAD_TOL[dtype], worst
+            if dtype == "bf16":
+                keys = [k for k in g["grad0"] if not (k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"))]
+                a = torch.cat([m.grad(k).cpu().flatten() for k in keys])
+                b = torch.cat([g["grad0"][k].flatten() for k in keys])
+                cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+                assert cos > BF16_MIN_COSINE, cos
+        opt.step()
+        opt.zero_grad()
+    if dtype == "fp32":
+        sd = m.state_dict()
+        for k, v in g["sd_final"].items():
+            if v.dtype == torch.int64:
+                assert int(sd[k]) == int(v), k
+            elif k.endswith("running_mean") or k.endswith("running_var"):
+                assert torch.allclose(sd[k].cpu(), v, rtol=1e-4, atol=1e-5), k
+            else:
+                # Adam divides by sqrt(v): an element whose gradient is rounding noise moves by +-lr per step in
+                # either implementation, so bound the outliers and require the bulk to agree tightly
+                d = (sd[k].cpu() - v).abs()
+                assert float(d.max()) <= 2.5 * float(g["lr"]) * int(g["steps"]), (k, float(d.max()))
+                assert float((d > 2e-4 + 2e-3 * v.abs()).float().mean()) < 5e-3, k
