@@ -1,0 +1,344 @@
+"""``DNANet_UNet`` -- the reference's model API on top of the MI355X kernels.
+
+Mirrors ``DNAnet/models/base.py:14-51`` (``Model`` / ``TrainableModel``) and
+``DNAnet/models/segmentation/trainable_unet.py:33-470`` (``DNANet_UNet``): same constructor keywords,
+``predict`` / ``predict_batch`` / ``predict_raw`` / ``sigmoid`` / ``get_inputs`` / ``get_targets`` /
+``fit`` (same keyword arguments, defaults and ``TypeError``s) / ``epoch`` / ``step`` / ``save`` / ``load``
+and the ``_model`` / ``_device`` / ``loss_fn`` / ``allele_caller`` attributes, and the same
+``DNANet_UNet_checkpoint.pt`` state-dict wire format.  The arithmetic runs in ``HipUNet``
+(``dnanet_amd/unet.py``); nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import shutil
+from abc import ABC, abstractmethod
+from collections import defaultdict
+from itertools import islice
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+from .allele_caller import NearestBasePairCaller
+from .data import chunks
+from .prediction import Prediction
+from .unet import ExponentialLR, HipAdam, HipUNet
+
+LOGGER = logging.getLogger("dnanet")
+TORCH_DEFAULT_DEVICE = "cuda" if torch.cuda.is_available() else "cpu"     # base.py:11
+
+try:  # optional experiment tracking, as in trainable_unet.py:212,239-241 (a no-op when not installed)
+    import mlflow as _mlflow
+except Exception:  # pragma: no cover
+    _mlflow = None
+
+try:
+    from tqdm import tqdm as _tqdm
+except Exception:  # pragma: no cover
+    _tqdm = None
+
+
+def _log_metric(key, value, step):
+    if _mlflow is not None:
+        try:
+            _mlflow.log_metric(key=key, value=value, step=step)
+        except Exception:  # pragma: no cover
+            pass
+
+
+class Model(ABC):
+    @abstractmethod
+    def predict(self, image) -> Prediction:
+        raise NotImplementedError
+
+    def predict_batch(self, batch: Sequence) -> Sequence[Prediction]:
+        return list(map(self.predict, batch))
+
+    @abstractmethod
+    def save(self, model_dir):
+        raise NotImplementedError
+
+    @abstractmethod
+    def load(self, model_dir):
+        raise NotImplementedError
+
+
+class TrainableModel(Model, ABC):
+    @abstractmethod
+    def fit(self, dataset, **kwargs):
+        raise NotImplementedError
+
+
+class BinaryAccuracy:
+    """``torchmetrics.classification.BinaryAccuracy`` (threshold 0.5) as the reference uses it
+    (``trainable_unet.py:295-303,411-415``); fed by the counts the fused Dice kernel produces."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.correct, self.total = 0.0, 0
+
+    def update_counts(self, correct: float, total: int):
+        self.correct += float(correct)
+        self.total += int(total)
+
+    def update(self, probabilities: torch.Tensor, target: torch.Tensor):
+        self.update_counts(float(((probabilities >= 0.5) == (target != 0)).sum()), target.numel())
+
+    def compute(self) -> float:
+        return self.correct / self.total if self.total else 0.0
+
+    def to(self, device):
+        return self
+
+    def __repr__(self):
+        return "BinaryAccuracy()"
+
+
+class _Loss:
+    """What ``step`` returns: behaves like the scalar loss tensor of the reference's loop
+    (``loss.backward()``, ``float(loss)``, ``trainable_unet.py:340-347``)."""
+
+    def __init__(self, model: HipUNet, sums: torch.Tensor, count: int, metrics=None):
+        self._model, self.sums, self.count = model, sums, count
+        self._metrics = list(metrics or [])
+        self._value = None
+
+    def backward(self):
+        self._model.backward()
+
+    def item(self) -> float:
+        if self._value is None:
+            host = self.sums.cpu()                   # the one device->host sync of a step
+            self._value = float(host[4])
+            for metric in self._metrics:             # accuracy counts came out of the same kernel pass
+                metric.update_counts(float(host[3]), self.count)
+        return self._value
+
+    __float__ = item
+
+    def detach(self):
+        return self
+
+
+class DNANet_UNet(TrainableModel):
+    def __init__(self, depth: int, kernel_size: Tuple[int, int], num_filters: int = 64, device: Optional[str] = None,
+                 apply_allele_caller: Optional[bool] = True, dtype: str = "fp32"):
+        """Same keywords as the reference (``trainable_unet.py:38-58``); ``dtype`` ("fp32" | "bf16") selects
+        exact-fp32 MFMA (default, reference numerics) or bf16 MFMA with fp32 accumulation."""
+        self._device = device or TORCH_DEFAULT_DEVICE
+        # On a 'cpu' device only the parameter tree exists (checkpoint I/O, config plumbing); any forward raises.
+        self._model = HipUNet(depth, tuple(kernel_size), num_filters, self._device, dtype=dtype)
+        self.loss_fn = self._dice
+        self.allele_caller = NearestBasePairCaller() if apply_allele_caller else None
+
+    # ---- tensorisation (trainable_unet.py:60-89) ---------------------------------------------------
+    @staticmethod
+    def get_input(image) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(np.transpose(np.asarray(image.data), (2, 0, 1)), dtype=np.float32))
+
+    def get_inputs(self, images: Sequence) -> torch.Tensor:
+        """(N,1,H,W) fp32 on the device.  int16-representable data crosses PCIe as int16 (half the bytes,
+        one copy for the whole batch) and is widened on the GPU."""
+        arr = np.stack([np.asarray(im.data) for im in images])               # (N,H,W,1)
+        arr = np.ascontiguousarray(np.transpose(arr, (0, 3, 1, 2)))
+        if arr.dtype.kind in "iu" and arr.size and int(arr.min()) >= -32768 and int(arr.max()) <= 32767:
+            src = torch.from_numpy(arr.astype(np.int16, copy=False)).to(self._device, non_blocking=True)
+            out = torch.empty(arr.shape, dtype=torch.float32, device=self._device)
+            hip.check(hip.lib.dn_i16_to_f32(hip.ptr(src), hip.ptr(out), out.numel(), hip.stream_ptr()))
+            return out
+        return torch.from_numpy(arr.astype(np.float32, copy=False)).to(self._device)
+
+    def get_targets(self, images: Sequence) -> torch.Tensor:
+        arr = np.stack([np.asarray(im.annotation.image) for im in images])   # (N,H,W,1)
+        arr = np.ascontiguousarray(np.transpose(arr, (0, 3, 1, 2)))
+        return torch.from_numpy(arr).to(self._device)
+
+    # ---- loss ------------------------------------------------------------------------------------------
+    def _dice(self, logits: torch.Tensor, targets: torch.Tensor) -> _Loss:
+        """DiceLoss (``loss.py:9-20``) on the fused kernel."""
+        sums = self._model.dice_forward(logits, targets)
+        return _Loss(self._model, sums, logits.numel())
+
+    # ---- training (trainable_unet.py:91-369) -----------------------------------------------------------
+    def fit(self, dataset, batch_size: int = 4, num_epochs: int = 10, learning_rate: float = 0.005,
+            weight_decay: float = 0.0005, tensorboard: bool = False, validation_set=None,
+            min_delta: Optional[float] = 0.01, steps_per_epoch: Optional[int] = None, use_evaluation_metric: bool = True,
+            checkpoint_dir=None, save_best: bool = False, use_scheduler: bool = False, **kwargs):
+        if save_best:
+            if validation_set is None:
+                raise TypeError("`validation_set` is required when `save_best` is True")
+            if checkpoint_dir is None:
+                raise TypeError("`checkpoint_dir` is required when `save_best` is True")
+        optimizer = HipAdam(self._model, lr=learning_rate, weight_decay=weight_decay)
+        scheduler = None
+        if use_scheduler:
+            LOGGER.info(f"Setting up exponential scheduler, starting with learning rate {learning_rate}")
+            scheduler = ExponentialLR(optimizer, gamma=0.8)
+        metrics = self.set_up_metrics(use_evaluation_metric)
+        if isinstance(checkpoint_dir, str):
+            checkpoint_dir = Path(checkpoint_dir)
+        writer = None
+        if tensorboard:
+            if checkpoint_dir is None:
+                raise TypeError("`checkpoint_dir` is required when `tensorboard` is True")
+            tensorboard_dir = checkpoint_dir / "tensorboard"
+            os.makedirs(tensorboard_dir, exist_ok=True)
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                writer = SummaryWriter(log_dir=str(tensorboard_dir))
+                LOGGER.info(f"Tensorboard logs are written to {tensorboard_dir}")
+            except Exception:
+                LOGGER.warning("tensorboard is not installed; no logs are written")
+        if not steps_per_epoch:
+            steps_per_epoch = max(1, len(dataset) // batch_size)
+        steps_per_epoch_val = len(validation_set) // batch_size if validation_set else None
+        prev_best = (1., 0)
+        best_validation_loss = float("inf")
+        for epoch in range(num_epochs):
+            summary: Dict[str, Dict[str, float]] = defaultdict(dict)
+            descr = f"Epoch {epoch + 1}/{num_epochs}"
+            train_batches = islice(chunks(dataset, batch_size), steps_per_epoch)
+            training_loss = self.epoch(batches=train_batches, steps_per_epoch=steps_per_epoch, description=descr,
+                                       optimizer=optimizer, train=True, metrics=metrics)
+            _log_metric("training_loss", training_loss, epoch)
+            summary["Loss"]["training"] = training_loss
+            for metric in metrics:
+                result = metric.compute()
+                summary[metric.__class__.__name__]["training"] = result
+                LOGGER.info(f"{descr} - Training {metric.__class__.__name__.lower()}: {result:.6f}")
+            LOGGER.info(f"{descr} - Training loss: {training_loss:.6f}")
+            if validation_set:
+                validation_metric = self.compute_metric(metrics[0], validation_set, batch_size) if metrics else float("nan")
+                validation_loss = self.compute_validation_loss(validation_set, batch_size, descr, steps_per_epoch_val, metrics)
+                LOGGER.info(f"{descr} - Validation metric ({metrics[0] if metrics else None}): {validation_metric:.6f} | "
+                            f"Validation loss: {validation_loss:.6f}")
+                _log_metric("validation_loss", validation_loss, epoch)
+                _log_metric("validation_metric", validation_metric, epoch)
+                summary["Loss"]["validation"] = validation_loss
+                for metric in metrics:
+                    result = metric.compute()
+                    summary[metric.__class__.__name__]["validation"] = result
+                    LOGGER.info(f"{descr} - Validation {metric.__class__.__name__.lower()}: {result:.6f}")
+                if save_best and validation_loss < best_validation_loss:
+                    best_validation_loss = validation_loss
+                    self.save(checkpoint_dir / "best_model")
+                    LOGGER.info(f"Saved best model with loss {best_validation_loss:.6f} at epoch {epoch + 1}.")
+                if validation_loss < prev_best[0] - min_delta:
+                    prev_best = (validation_loss, epoch)
+                elif epoch - prev_best[1] > 5:
+                    LOGGER.info(f"Early stopping reached at epoch {epoch + 1}.")
+                    break
+            if scheduler is not None:
+                self.update_scheduler(descr, optimizer, scheduler)
+            if writer and summary:
+                for tag, scalars in summary.items():
+                    writer.add_scalars(tag, scalars, global_step=epoch + 1)
+                writer.flush()
+        if writer:
+            writer.close()
+        if save_best:
+            self.load(checkpoint_dir / "best_model")
+            shutil.rmtree(checkpoint_dir / "best_model")
+            LOGGER.info("Restored previous best model")
+
+    def set_up_metrics(self, use_evaluation_metric: bool) -> List[BinaryAccuracy]:
+        return [BinaryAccuracy()] if use_evaluation_metric else []
+
+    @staticmethod
+    def update_scheduler(descr: str, optimizer: HipAdam, scheduler: ExponentialLR):
+        scheduler.step()
+        LOGGER.info(f"{descr}: scheduler decreased learning rate to {optimizer.param_groups[0]['lr']}")
+
+    def epoch(self, batches: Iterator[Sequence], steps_per_epoch: int, description: str, optimizer: Optional[HipAdam] = None,
+              train: bool = True, metrics: Sequence[BinaryAccuracy] = None) -> float:
+        if _tqdm is not None:
+            batches = _tqdm(batches, desc=description, total=steps_per_epoch)
+        if train:
+            self._model.train()
+            optimizer.zero_grad()
+        else:
+            self._model.eval()
+        for metric in metrics or []:
+            metric.reset()
+        epoch_loss = 0.
+        for step, batch in enumerate(batches):
+            loss = self.step(batch, metrics)
+            if train:
+                loss.backward()
+                optimizer.step()
+                optimizer.zero_grad()
+            epoch_loss = (epoch_loss * step + float(loss)) / (step + 1)
+            if _tqdm is not None and isinstance(batches, _tqdm):
+                batches.set_postfix({("training" if train else "validation") + "_loss": epoch_loss})
+        return epoch_loss
+
+    def step(self, batch: Sequence, metrics: Optional[Sequence[BinaryAccuracy]]) -> _Loss:
+        inputs = self.get_inputs(batch)
+        y_true = self.get_targets(batch)
+        logits = self._model(inputs)
+        loss = self.loss_fn(logits, y_true)
+        loss._metrics = list(metrics or [])      # resolved with the loss value (one sync, after the step is queued)
+        return loss
+
+    # ---- inference (trainable_unet.py:371-409) ---------------------------------------------------------
+    def predict(self, image) -> Prediction:
+        return self.predict_batch([image])[0]
+
+    def predict_batch(self, batch: Sequence) -> List[Prediction]:
+        self._model.eval()
+        batch = list(batch)
+        inputs = self.get_inputs(batch)
+        _, probs = self._model.infer(inputs, want_logits=False, want_probs=True)
+        host = probs.movedim(1, -1).cpu().numpy()                      # (N,H,W,1): one D->H copy for the batch
+        predictions = [Prediction(image=host[i], meta={"original_image_path": getattr(image, "path", None)})
+                       for i, image in enumerate(batch)]
+        if self.allele_caller:
+            LOGGER.info("Calling alleles from predicted segmentation...")
+            predictions = [self.allele_caller.call_alleles(im, pred) for im, pred in zip(batch, predictions)]
+        return predictions
+
+    def predict_raw(self, images: Sequence) -> torch.Tensor:
+        return self._model(self.get_inputs(images))
+
+    @staticmethod
+    def sigmoid(logits: torch.Tensor) -> torch.Tensor:
+        return torch.sigmoid(logits)
+
+    def update_metric(self, metric: BinaryAccuracy, logits: torch.Tensor, y_true: torch.Tensor):
+        metric.update(torch.flatten(self.sigmoid(logits)), torch.flatten(y_true))
+
+    def compute_metric(self, metric: BinaryAccuracy, dataset, batch_size: int) -> float:
+        """As the reference (``trainable_unet.py:417-432``) this runs in whatever mode the model is in --
+        train mode right after a training epoch, so BatchNorm statistics see these batches too."""
+        metric.reset()
+        for batch in chunks(dataset, batch_size):
+            y_true = self.get_targets(batch)
+            logits = self._model(self.get_inputs(batch))
+            sums = self._model.dice_forward(logits, y_true)
+            metric.update_counts(float(sums[3]), logits.numel())
+        self._model._saved = None
+        return metric.compute()
+
+    def compute_validation_loss(self, validation_set, batch_size: int, description: str, steps_per_epoch: int,
+                                metrics: Sequence[BinaryAccuracy]) -> float:
+        return self.epoch(chunks(validation_set, batch_size), steps_per_epoch=steps_per_epoch, description=description,
+                          train=False, metrics=metrics)
+
+    # ---- checkpoints (trainable_unet.py:447-470) -------------------------------------------------------
+    def save(self, model_dir):
+        os.makedirs(model_dir, exist_ok=True)
+        state = {k: v.detach().cpu().clone() for k, v in self._model.state_dict().items()}
+        torch.save(state, self._get_weights_path(model_dir))
+
+    def load(self, model_dir):
+        state = torch.load(self._get_weights_path(model_dir), map_location="cpu", weights_only=True)
+        self._model.load_state_dict(state)
+
+    def _get_weights_path(self, model_dir) -> str:
+        return os.path.join(model_dir, f"{self.__class__.__name__}_checkpoint.pt")

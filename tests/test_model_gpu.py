@@ -1,0 +1,110 @@
+"""The reference's model API end to end on the GPU: predict_batch -> Prediction -> allele caller, and fit()."""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(x, t=None, panel=None):
+    from dnanet_amd.data import Annotation, ArrayImage
+    out = []
+    for i in range(x.shape[0]):
+        data = np.transpose(x[i], (1, 2, 0)).astype(np.int16)                   # (H,W,1) like HIDImage.data
+        ann = Annotation(image=np.transpose(t[i], (1, 2, 0)).astype(np.int8)) if t is not None else None
+        out.append(ArrayImage(data=data, annotation=ann, path=f"profile_{i}.hid", _scaler=np.linspace(65, 475, x.shape[3]),
+                              _panel=panel))
+    return out
+
+
+def test_predict_batch_real_profiles_probabilities_masks_alleles(gpu_device):
+    """The two real RD profiles of the reference's test resources through predict_batch (fp32 mode):
+    probabilities within tolerance of the reference's, masks and called alleles identical."""
+    from dnanet_amd.allele_caller import NearestBasePairCaller
+    from dnanet_amd.data import Panel
+    from dnanet_amd.model import DNANet_UNet
+    g = load_golden("g_real_d4_k35_f8")
+    panel = Panel(os.path.join(GOLDEN_DIR, "panel.xml"))
+    model = DNANet_UNet(4, (3, 5), 8, device="cuda", apply_allele_caller=True)
+    model._model.load_state_dict(g["sd0"])
+    images = _images(g["x"], g["t"], panel)
+    preds = model.predict_batch(images)
+    ref_probs = torch.sigmoid(torch.from_numpy(g["logits_eval"])).numpy()
+    for i, p in enumerate(preds):
+        assert p.image.shape == (5, 4096, 1) and p.image.dtype == np.float32
+        assert p.meta["original_image_path"] == f"profile_{i}.hid"
+        ref = np.transpose(ref_probs[i], (1, 2, 0))
+        assert np.abs(p.image - ref).max() < 1e-5
+        assert np.array_equal(p.image >= 0.5, ref >= 0.5)
+        expect = NearestBasePairCaller().translate_pixels_to_alleles(images[i]._scaler[None], ref, images[i].data, panel)
+        got = p.meta["called_alleles"]
+        key = lambda ms: sorted((m.dye_row, m.name, tuple(sorted((a.name, a.height) for a in m.alleles))) for m in ms)
+        assert key(got) == key(expect)
+    # predict() == predict_batch()[0]
+    one = model.predict(images[1])
+    assert np.array_equal(one.image, preds[1].image)
+
+
+def test_predict_batch_bf16_mask_agreement(gpu_device):
+    from dnanet_amd.model import DNANet_UNet
+    g = load_golden("g_real_d4_k35_f8")
+    model = DNANet_UNet(4, (3, 5), 8, device="cuda", apply_allele_caller=False, dtype="bf16")
+    model._model.load_state_dict(g["sd0"])
+    preds = model.predict_batch(_images(g["x"]))
+    ref = torch.sigmoid(torch.from_numpy(g["logits_eval"])).numpy()
+    agree = np.mean([(np.transpose(ref[i], (1, 2, 0)) >= 0.5) == (p.image >= 0.5) for i, p in enumerate(preds)])
+    assert agree > 0.995, agree       # bf16 mode: reported agreement, not identity
+
+
+def test_fit_loop_matches_oracle_loop(gpu_device):
+    """fit(): chunking, dropped remainder, per-epoch ExponentialLR, Adam -- against the oracle's restatement of the
+    reference loop (trainable_unet.py:183-203,273-274,339-347)."""
+    from dnanet_amd.model import DNANet_UNet
+    from oracle import unet_oracle as O
+    g = load_golden("g_d2_k35_f8_h5_w64")
+    rng = np.random.default_rng(5)
+    x = np.concatenate([g["x"], np.abs(rng.normal(0, 300, size=(3, 1, 5, 64))).round().astype(np.float32)])
+    t = np.concatenate([g["t"], (rng.random((3, 1, 5, 64)) < 0.1).astype(np.int8)])
+    images = _images(x, t)
+    model = DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False)
+    model._model.load_state_dict(g["sd0"])
+    model.fit(images, batch_size=2, num_epochs=2, learning_rate=1e-3, use_scheduler=True)
+    sd = OrderedDict((k, v.clone()) for k, v in g["sd0"].items())
+    state = O.AdamState(O.trainable_keys(sd), sd)
+    for epoch in range(2):
+        lr = O.exponential_lr(1e-3, epoch)
+        for s in range(len(images) // 2):              # 5 images, batch 2 -> 2 steps, the 5th image is never used
+            xs = torch.from_numpy(x[2 * s:2 * s + 2]); ts = torch.from_numpy(t[2 * s:2 * s + 2])
+            O.train_step(sd, xs, ts, state, lr, 5e-4)
+    got = model._model.state_dict()
+    for k, v in sd.items():
+        if v.dtype == torch.int64:
+            assert int(got[k]) == int(v) == 4
+        elif "running" in k:
+            assert torch.allclose(got[k].cpu(), v, rtol=1e-4, atol=1e-5), k
+        else:
+            d = (got[k].cpu() - v).abs()
+            assert float(d.max()) <= 2.5 * 1e-3 * 4 and float((d > 2e-4 + 2e-3 * v.abs()).float().mean()) < 1e-2, k
+
+
+def test_fit_learns_and_checkpoints(gpu_device, tmp_path):
+    from dnanet_amd.model import DNANet_UNet
+    from dnanet_amd.synthetic import make_batch
+    x, t = make_batch(12, 5, 256, seed=3, unique=12)
+    images = _images(x, t)
+    model = DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False, dtype="bf16")
+    before = model.compute_validation_loss(images[8:], 4, "val", 1, [])
+    model.fit(images[:8], batch_size=4, num_epochs=6, learning_rate=5e-3, validation_set=images[8:], min_delta=-99999,
+              checkpoint_dir=str(tmp_path), save_best=True, use_scheduler=True)
+    after = model.compute_validation_loss(images[8:], 4, "val", 1, [])
+    assert after < before - 0.02, (before, after)
+    assert not (tmp_path / "best_model").exists()      # restored and removed (trainable_unet.py:290-293)
+    model.save(tmp_path / "final")
+    sd = torch.load(tmp_path / "final" / "DNANet_UNet_checkpoint.pt", weights_only=True)
+    assert len(sd) == 7 * 10 + 2 * 2 + 2
