@@ -69,6 +69,52 @@ def cpu_baseline(rows: int, seconds_budget: float = 20.0):
             "sample": f"{done} synthetic {rows}x4096 profiles, eval forward in batches of {n}, torch fp32 oracle"}
 
 
+TRAIN_FLOP_H5 = 175_574_876_160        # fwd + dgrad + wgrad per profile, H=5
+
+
+def train_leg(args, dev, rank, world, distributed, x, t, barrier):
+    """fwd (batch-stat BN) + Dice + bwd + Adam on the same synthetic batch; data parallel over RCCL when N > 1
+    (global batch = 256 x N, Dice sums and the gradient arena all-reduced; BASELINE.json configs[2]/[3])."""
+    from dnanet_amd.unet import HipAdam, HipUNet
+    torch.manual_seed(0)
+    model = HipUNet(4, (3, 5), 32, dev, dtype=args.dtype)
+    model.train()
+    opt = HipAdam(model, lr=1e-4, weight_decay=5e-4)
+    if distributed:
+        from dnanet_amd.distributed import DataParallelTrainer
+        trainer = DataParallelTrainer(model, opt)
+        step = lambda: trainer.step(x, t)
+    else:
+        def step():
+            logits = model(x)
+            sums = model.dice_forward(logits, t)
+            model.backward()
+            opt.step()
+            opt.zero_grad()
+            return sums
+    steps = max(3, args.steps // 4)
+    for _ in range(2):
+        sums = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sums = step()
+    loss = float(sums[4])              # the per-step host sync of the reference loop (trainable_unet.py:347), once here
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    pps = args.batch * world * steps / elapsed
+    peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
+    return {"value": round(pps, 1), "unit": "profiles/s", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "global_batch": args.batch * world, "loss": round(loss, 5),
+            "parallelism": f"dp{world}" + (" (RCCL sum-all-reduce of Dice sums + bucketed gradient arena)" if world > 1 else ""),
+            "whole_step_mfma_frac": round(pps / world * TRAIN_FLOP_H5 * args.rows / 5 / 1e12 / peak, 4)}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +194,8 @@ def main():
                    "parallelism": f"replicas x{world} (inference shards by profile, no collective)"},
         "roofline": roofline,
     }
+    if not args.no_train:
+        out["train_step"] = train_leg(args, dev, rank, world, distributed, x, torch.from_numpy(t_np).to(dev), barrier)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.rows)
     if rank == 0:

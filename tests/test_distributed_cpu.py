@@ -1,0 +1,76 @@
+"""The N>1 logic under gloo, world_size 2, on CPU: shard ranges, segment order / bucketing of the gradient
+arena, sum-all-reduce, global Dice sums."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dnanet_amd.distributed import ArenaAllReducer, all_reduce_dice_sums, module_segments, shard_range
+from dnanet_amd.params import ParameterTree
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 256, 348):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_segments_cover_arena_in_backward_order():
+    tree = ParameterTree(4, (3, 5), 32, "cpu")
+    segs = module_segments(tree.offsets, 4, tree.flat_params.numel())
+    assert [s[0] for s in segs] == ["head", "decoders.3", "decoders.2", "decoders.1", "decoders.0", "bottleneck",
+                                    "encoders.3", "encoders.2", "encoders.1", "encoders.0"]
+    spans = sorted((a, b) for _, a, b in segs)
+    assert spans[0][0] == 0 and spans[-1][1] == tree.flat_params.numel()
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))     # contiguous, disjoint
+    big = {n: b - a for n, a, b in segs}
+    assert (big["bottleneck"] + big["decoders.0"]) / tree.n_param > 0.7            # ~75 % of the bytes
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tree = ParameterTree(2, (3, 5), 8, "cpu")
+        segs = module_segments(tree.offsets, 2, tree.flat_grads.numel())
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(tree.flat_grads.numel(), generator=g)
+        tree.flat_grads.copy_(local)
+        red = ArenaAllReducer(tree.flat_grads, segs, min_bucket_elems=20000)
+        for name, _, _ in segs:                       # the order backward reports segments
+            red.segment_done(name)
+        launched = red.finish()
+        other = torch.randn(tree.flat_grads.numel(), generator=torch.Generator().manual_seed(100 + (1 - rank)))
+        ok_sum = torch.allclose(tree.flat_grads, local + other)
+        covered = sorted(launched)
+        ok_cover = covered[0][0] == 0 and covered[-1][1] == tree.flat_grads.numel() and \
+            all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+        sums = torch.tensor([1.0 + rank, 10.0, 3.0, 50.0, 0.0, 0, 0, 0])
+        gs = all_reduce_dice_sums(sums)
+        ok_dice = torch.allclose(gs[:4], torch.tensor([3.0, 20.0, 6.0, 100.0])) and \
+            abs(float(gs[4]) - (1 - (2 * 3 + 1) / (20 + 6 + 1))) < 1e-6
+        q.put((rank, ok_sum, ok_cover, len(launched), ok_dice))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_all_reduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_sum, ok_cover, nb, ok_dice in res:
+        assert ok_sum and ok_cover and ok_dice, (rank, ok_sum, ok_cover, ok_dice)
+        assert 1 < nb < 6          # a handful of buckets, not one per tensor

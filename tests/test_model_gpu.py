@@ -108,3 +108,34 @@ def test_fit_learns_and_checkpoints(gpu_device, tmp_path):
     model.save(tmp_path / "final")
     sd = torch.load(tmp_path / "final" / "DNANet_UNet_checkpoint.pt", weights_only=True)
     assert len(sd) == 7 * 10 + 2 * 2 + 2
+
+
+def test_data_parallel_step_world1_equals_plain_step(gpu_device):
+    """The DP trainer (RCCL process group of one rank here) must reproduce the plain step bit for bit."""
+    import torch.distributed as dist
+    from dnanet_amd.distributed import DataParallelTrainer
+    from dnanet_amd.unet import HipAdam, HipUNet
+    g = load_golden("g_d2_k35_f8_h5_w64")
+    x, t = torch.from_numpy(g["x"]).to(gpu_device), torch.from_numpy(g["t"]).to(gpu_device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        results = []
+        for dp in (False, True):
+            m = HipUNet(2, (3, 5), 8, gpu_device, dtype="fp32")
+            m.load_state_dict(g["sd0"])
+            m.train()
+            opt = HipAdam(m, lr=1e-3, weight_decay=5e-4)
+            if dp:
+                tr = DataParallelTrainer(m, opt, min_bucket_elems=10000)
+                for _ in range(2):
+                    sums = tr.step(x, t)
+            else:
+                for _ in range(2):
+                    logits = m(x); sums = m.dice_forward(logits, t); m.backward(); opt.step(); opt.zero_grad()
+            results.append((m.flat_params.clone(), float(sums[4])))
+        assert torch.equal(results[0][0], results[1][0])
+        assert abs(results[0][1] - results[1][1]) < 1e-7
+    finally:
+        dist.destroy_process_group()
