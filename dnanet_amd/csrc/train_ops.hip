@@ -53,6 +53,15 @@ __device__ __forceinline__ void block_reduce_store(float (&acc)[KV][PN], float* 
   }
 }
 
+// One 64-lane wave per channel sums `nblk` partials in fp64 in a fixed order (lane-strided, then a shuffle tree).
+__device__ __forceinline__ double wave_sum_partials(const float* partial, int nblk, long stride, long offset) {
+  double s = 0;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[(long)b * stride + offset];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  return s;
+}
+
 // ---- BatchNorm statistics: sum(y), sum(y^2) --------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned char* y, int planes_total, int plane0, long N,
@@ -75,11 +84,11 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned ch
 __global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                    float* mean_out, float* invstd_out, float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cpad) return;
-  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f; return; }
-  double s = 0, ss = 0;
-  for (int b = 0; b < nblk; ++b) { s += partial[((long)b * cpad + c) * 2]; ss += partial[((long)b * cpad + c) * 2 + 1]; }
+  const int c = blockIdx.x;       // one wave per channel
+  if (c >= C) { if (threadIdx.x == 0) { scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
+  const double s = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2);
+  const double ss = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2 + 1);
+  if (threadIdx.x != 0) return;
   const double mean = s / count;
   double var = ss / count - mean * mean;
   if (var < 0) var = 0;
@@ -152,11 +161,11 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsign
 
 __global__ void bn_bwd_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count, const float* gamma,
                                        const float* invstd, float* dgamma, float* dbeta, float* coef /*[3][cpad]*/) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cpad) return;
-  if (c >= C) { coef[c] = 0.f; coef[cpad + c] = 0.f; coef[2 * cpad + c] = 0.f; return; }
-  double s1 = 0, s2 = 0;
-  for (int b = 0; b < nblk; ++b) { s1 += partial[((long)b * cpad + c) * 2]; s2 += partial[((long)b * cpad + c) * 2 + 1]; }
+  const int c = blockIdx.x;       // one wave per channel
+  if (c >= C) { if (threadIdx.x == 0) { coef[c] = 0.f; coef[cpad + c] = 0.f; coef[2 * cpad + c] = 0.f; } return; }
+  const double s1 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2);
+  const double s2 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2 + 1);
+  if (threadIdx.x != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   coef[c] = gamma[c] * invstd[c];            // s
@@ -278,11 +287,10 @@ __global__ __launch_bounds__(RED_THREADS) void channel_sum_kernel(const unsigned
 }
 
 __global__ void channel_sum_finalize_kernel(const float* partial, int nblk, int cpad, int C, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x;       // one wave per channel
   if (c >= C) return;
-  double s = 0;
-  for (int b = 0; b < nblk; ++b) s += partial[(long)b * cpad + c];
-  out[c] = (float)s;
+  const double s = wave_sum_partials(partial, nblk, cpad, c);
+  if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 // ---- first-convolution weight gradient: dW[co][tap] = sum_pix dy[pix][co] * x[pix + tap] ------------
@@ -327,12 +335,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
 }
 
 __global__ void conv_first_wgrad_finalize_kernel(const float* partial, int nblk, int taps, int cpad, int C, float* dw /*[C][taps]*/) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x;       // one wave per (channel, tap)
   if (i >= C * taps) return;
   const int c = i / taps, t = i % taps;
-  double s = 0;
-  for (int b = 0; b < nblk; ++b) s += partial[((long)b * taps + t) * cpad + c];
-  dw[i] = (float)s;
+  const double s = wave_sum_partials(partial, nblk, (long)taps * cpad, (long)t * cpad + c);
+  if (threadIdx.x == 0) dw[i] = (float)s;
 }
 
 // ---- Dice loss ------------------------------------------------------------------------------------------
@@ -362,10 +369,9 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const float* __restrict__
 
 // sums[0..3] = I, P, T, correct (fp32, fp64-accumulated); sums[4] = loss of THESE sums (local batch)
 __global__ void dice_finalize_kernel(const float* partial, int nblk, float* sums, float smooth) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s[4] = {0, 0, 0, 0};
-  for (int b = 0; b < nblk; ++b)
-    for (int k = 0; k < 4; ++k) s[k] += partial[(long)b * 4 + k];
+  double s[4];
+  for (int k = 0; k < 4; ++k) s[k] = wave_sum_partials(partial, nblk, 4, k);
+  if (threadIdx.x != 0) return;
   for (int k = 0; k < 4; ++k) sums[k] = (float)s[k];
   sums[4] = (float)(1.0 - (2.0 * s[0] + smooth) / (s[1] + s[2] + smooth));
 }
@@ -414,10 +420,8 @@ __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restric
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void sum_finalize_kernel(const float* partial, int nblk, float* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0;
-  for (int b = 0; b < nblk; ++b) s += partial[b];
-  out[0] = (float)s;
+  const double s = wave_sum_partials(partial, nblk, 1, 0);
+  if (threadIdx.x == 0) out[0] = (float)s;
 }
 
 inline unsigned ew_grid(long total) { return (unsigned)std::min<long>((total + 255) / 256, 8192); }
@@ -448,7 +452,7 @@ int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const flo
     hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (long)N, HW, partial, cpad),
     "dn_bn_train_forward");
   DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((cpad + 63) / 64), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   DN_LAUNCH_CHECK();
   const long total = (long)N * nplanes * HW * 2;
@@ -477,7 +481,7 @@ int dn_bn_train_backward(dn_tensor g, dn_tensor y, dn_tensor a, int N, int H, in
     "dn_bn_train_backward");
 #undef ARGS_R
   DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((cpad + 63) / 64), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma,
                      invstd, dgamma, dbeta, coef);
   DN_LAUNCH_CHECK();
   const long total = (long)N * nplanes * HW * 2;
@@ -530,7 +534,7 @@ int dn_head_1x1_backward(const float* dlogits, dn_tensor x, const float* w, dn_t
     hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, (long)N, HW, dlogits, partial, cpad),
     "dn_head_1x1_backward");
   DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, nblk, cpad, C, dw);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(64), 0, s, partial, nblk, cpad, C, dw);
   DN_LAUNCH_CHECK();
   // bias gradient = sum(dlogits): reuse the Dice reduction shape via a 1-plane trick is overkill; a tiny kernel does it
   float* p2 = partial + (long)nblk * cpad;
@@ -553,7 +557,7 @@ int dn_channel_sum(dn_tensor x, float* out, float* partial, int N, int H, int W,
     hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, (long)N, HW, (const float*)nullptr, partial, cpad),
     "dn_channel_sum");
   DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, nblk, cpad, C, out);
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(64), 0, s, partial, nblk, cpad, C, out);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }
@@ -572,7 +576,7 @@ int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial,
   else return dn_set_error(DN_ERR_UNSUPPORTED, "dn_conv_first_wgrad: kernel size (%d,%d) not built", kh, kw);
 #undef LAUNCH
   DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(conv_first_wgrad_finalize_kernel, dim3((C * taps + 63) / 64), dim3(64), 0, s, partial, nblk, taps, cpad, C, dw);
+  hipLaunchKernelGGL(conv_first_wgrad_finalize_kernel, dim3(C * taps), dim3(64), 0, s, partial, nblk, taps, cpad, C, dw);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

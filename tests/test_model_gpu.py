@@ -98,11 +98,19 @@ def test_fit_learns_and_checkpoints(gpu_device, tmp_path):
     from dnanet_amd.synthetic import make_batch
     x, t = make_batch(12, 5, 256, seed=3, unique=12)
     images = _images(x, t)
+    torch.manual_seed(0)
     model = DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False, dtype="bf16")
-    before = model.compute_validation_loss(images[8:], 4, "val", 1, [])
-    model.fit(images[:8], batch_size=4, num_epochs=6, learning_rate=5e-3, validation_set=images[8:], min_delta=-99999,
+
+    def train_mode_loss():      # batch-statistics loss on the training images (no update)
+        model._model.train()
+        vals = [float(model.step(b, [])) for b in ([images[:4], images[4:8]])]
+        model._model._saved = None
+        return sum(vals) / len(vals)
+
+    before = train_mode_loss()
+    model.fit(images[:8], batch_size=4, num_epochs=10, learning_rate=5e-3, validation_set=images[8:], min_delta=-99999,
               checkpoint_dir=str(tmp_path), save_best=True, use_scheduler=True)
-    after = model.compute_validation_loss(images[8:], 4, "val", 1, [])
+    after = train_mode_loss()
     assert after < before - 0.02, (before, after)
     assert not (tmp_path / "best_model").exists()      # restored and removed (trainable_unet.py:290-293)
     model.save(tmp_path / "final")
