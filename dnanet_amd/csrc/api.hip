@@ -1,6 +1,7 @@
 // C-ABI glue: error text, convolution dispatch. See include/dnanet_hip.h.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "ops.h"
 
@@ -15,9 +16,11 @@ int dn_set_error(int code, const char* fmt, ...) {
 }
 
 static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t s) {
-  const int cot = (p.cout_pad % 64 == 0) ? 64 : 32;
+  int cot = (p.cout_pad % 64 == 0) ? 64 : 32;
   int ht = 5;
-  if (kh == 3 && kw == 5 && p.H % 6 == 0 && p.H % 5 != 0) ht = 6;
+  if (kh == 3 && kw == 5 && p.H % 3 == 0 && p.H % 5 != 0) ht = 3;   // e.g. 6 dye rows = two 3-row tiles
+  static const char* force_cot = getenv("DN_TUNE_COT");      // tuning aid: DN_TUNE_COT=32 forces the narrow tile
+  if (force_cot && atoi(force_cot) == 32) cot = 32;
   if (dtype == DN_BF16) {
     if (kh == 3 && kw == 5) return conv_igemm_run_bf16_k35(p, ht, cot, s);
     if (kh == 1 && kw == 3) return conv_igemm_run_bf16_k13(p, ht, cot, s);

@@ -18,6 +18,9 @@
 #pragma once
 #include "common.h"
 
+// source of zero-filled LDS pieces (image borders, padding)
+__device__ __attribute__((aligned(16))) const unsigned int dn_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 struct ConvParams {
   const void* x; int x_planes_total, x_plane0, x_nplanes, x_gplanes, x_wmul;
   const void* w;            // packed [nchunk][TAPS][cout_pad][32 B]
@@ -56,11 +59,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   constexpr int EPR = RecTraits<T>::EPR;
   constexpr int ACT_BYTES = ROWS * QW * 32;
   constexpr int W_BYTES = TAPS * COT * 32;
-  constexpr int XP = 2 * (KW - 1);          // pieces per tile row beyond the first 256
-  constexpr int TPI = 128 / COT;            // taps staged per 256-piece pass
-  constexpr int W_ITERS = (TAPS + TPI - 1) / TPI;
-  constexpr int SB = 4;   // staging batch (pieces per thread in flight)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + W_BYTES];
+  constexpr int ACT_PIECES = ACT_BYTES / 16, W_PIECES = W_BYTES / 16;
+  constexpr int ST_ITERS = (ACT_PIECES + W_PIECES + 255) / 256;     // wave-instructions of 1 KiB per wave
+  constexpr int EPI_BYTES = 4 * (COT / EPR) * 1024;                 // epilogue scratch: 4 waves x planes x 1 KiB
+  constexpr int SMEM_BYTES = ST_ITERS * 4096 > EPI_BYTES ? ST_ITERS * 4096 : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -75,22 +78,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const int w0 = tw * 128, h0 = th * HT;
   const int xrow = p.W * p.x_wmul;
 
-  // per-thread staging offsets (bytes)
-  const int a_q = tid >> 1, a_pc = tid & 1;
-  const int a_w = w0 + a_q - PW;
-  const bool a_ok = a_w >= 0 && a_w < p.W;
-  const long a_goff = ((long)a_w * p.x_wmul) * 32 + 16 * a_pc;
-  const int a_loff = a_q * 32 + 16 * (a_pc ^ ((a_q >> 3) & 1));
-  const int x_r = XP > 0 ? tid / (XP > 0 ? XP : 1) : 0;
-  const int x_i = 256 + (XP > 0 ? tid % (XP > 0 ? XP : 1) : 0);
-  const int x_q = x_i >> 1, x_pc = x_i & 1;
-  const int x_w = w0 + x_q - PW;
-  const bool x_ok = x_w >= 0 && x_w < p.W;
-  const long x_goff = ((long)x_w * p.x_wmul) * 32 + 16 * x_pc;
-  const int x_loff = x_q * 32 + 16 * (x_pc ^ ((x_q >> 3) & 1));
-  const int w_tap = tid / (2 * COT), w_co = (tid >> 1) % COT, w_pc = tid & 1;
-  const long w_goff = ((long)w_tap * p.cout_pad + w_co) * 32 + 16 * w_pc;
-  const int w_loff = (w_tap * COT + w_co) * 32 + 16 * (w_pc ^ ((w_co >> 3) & 1));
+  // per-thread staging plan: LDS piece P = (it*4 + wave)*64 + lane of the linear image [act tile | weight tile | pad];
+  // st_off[it] = byte offset of its source inside the current plane / weight block (-1: zero fill)
+  int st_off[ST_ITERS];
+  unsigned st_isw = 0;
+  {
+    const int xrow_b = p.W * p.x_wmul * 32;
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {
+      const int P = (it * 4 + wave) * 64 + lane;
+      int off = -1;
+      if (P < ACT_PIECES) {
+        const int rq = P >> 1, pcl = P & 1;
+        const int r = rq / QW, q = rq - r * QW;
+        const int h = h0 + r - PH, w = w0 + q - PW;
+        if (h >= 0 && h < p.H && w >= 0 && w < p.W) off = h * xrow_b + w * p.x_wmul * 32 + 16 * (pcl ^ ((q >> 3) & 1));
+      } else if (P < ACT_PIECES + W_PIECES) {
+        const int Pw = P - ACT_PIECES;
+        const int tc = Pw >> 1, pcl = Pw & 1;
+        const int tap = tc / COT, co = tc - tap * COT;
+        off = (tap * p.cout_pad + co) * 32 + 16 * (pcl ^ ((co >> 3) & 1));
+        st_isw |= 1u << it;
+      }
+      st_off[it] = off;
+    }
+  }
 
   f32x16_t acc[HT][NCG];
 #pragma unroll
@@ -109,56 +121,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     if (plane >= p.x_nplanes) continue;   // padding plane of a virtual group: weights are zero, data absent
     const long plane_base = ((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow;
     __syncthreads();   // previous chunk's fragment reads are done
-    // ---- stage the activation tile (rows h0-PH .. h0+HT-1+PH, columns w0-PW .. w0+127+PW).
-    // Thread t moves 16-byte piece t of every tile row (a row is QW*2 = 256 + 2*(KW-1) pieces); the
-    // few pieces past 256 are moved by threads 0..ROWS*XP-1 in one extra pass. Addresses are
-    // "uniform row base + per-thread offset", so nothing but two offsets lives across the K loop.
-    const unsigned char* xplane = xb + plane_base * 32 + (long)grp * 32;
-#pragma unroll
-    for (int r0 = 0; r0 < ROWS; r0 += SB) {
-      uint4 v[SB];
-#pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        const int r = r0 + k;
-        const int h = h0 + r - PH;
-        v[k] = make_uint4(0, 0, 0, 0);
-        if (r < ROWS && a_ok && h >= 0 && h < p.H) v[k] = *(const uint4*)(xplane + (long)h * xrow * 32 + a_goff);
-      }
-#pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        const int r = r0 + k;
-        if (r < ROWS) *(uint4*)(smem + r * QW * 32 + a_loff) = v[k];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (XP > 0) {
-      if (tid < ROWS * XP) {
-        const int h = h0 + x_r - PH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (x_ok && h >= 0 && h < p.H) v = *(const uint4*)(xplane + (long)h * xrow * 32 + x_goff);
-        *(uint4*)(smem + x_r * QW * 32 + x_loff) = v;
-      }
-    }
-    // ---- stage the weight tile [TAPS][COT] records of this chunk / output-channel tile
+    // ---- stage activation + weight tiles straight into LDS (global_load_lds_dwordx4: no VGPR round trip,
+    // all pieces of the chunk in flight at once).  The LDS image is lane-linear per wave-instruction, so the
+    // XOR swizzle is applied to the per-lane SOURCE address (cdna_hip_programming.md, rule 21).
     {
+      const unsigned char* xplane = xb + plane_base * 32 + (long)grp * 32;
       const unsigned char* wsrc = wb + ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32;
 #pragma unroll
-      for (int it0 = 0; it0 < W_ITERS; it0 += SB) {
-        uint4 v[SB];
-#pragma unroll
-        for (int k = 0; k < SB; ++k) {
-          const int tap = (it0 + k) * TPI + w_tap;
-          v[k] = make_uint4(0, 0, 0, 0);
-          if (it0 + k < W_ITERS && tap < TAPS) v[k] = *(const uint4*)(wsrc + (long)((it0 + k) * TPI) * p.cout_pad * 32 + w_goff);
-        }
-#pragma unroll
-        for (int k = 0; k < SB; ++k) {
-          const int tap = (it0 + k) * TPI + w_tap;
-          if (it0 + k < W_ITERS && tap < TAPS) *(uint4*)(smem + ACT_BYTES + (it0 + k) * 4096 + w_loff) = v[k];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int it = 0; it < ST_ITERS; ++it) {
+        const int off = st_off[it];
+        const unsigned char* src = (const unsigned char*)dn_zero_page;
+        if (off >= 0) src = ((st_isw >> it) & 1) ? wsrc + off : xplane + off;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (it * 4 + wave) * 1024), 16, 0, 0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- MFMA over all taps
 #pragma unroll
@@ -189,45 +167,54 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
   }
 
-  // ---- epilogue: bias (+ folded BN) + ReLU, store 4 consecutive channels per lane and group
-  const int wcol = w0 + 32 * wave + l31;
+  // ---- epilogue: bias (+ folded BN) + ReLU in registers, then through a wave-private LDS scratch so that
+  // every global store instruction writes 1 KiB of consecutive 16-byte pieces (32 pixels of one plane row)
+  // instead of 8-byte fragments at a 32-byte stride.
+  constexpr int NPL = COT / EPR;                    // output planes of this tile
+  __syncthreads();                                  // all waves are done reading the staged tiles
+  unsigned char* scratch = smem + wave * (NPL * 1024);
   unsigned char* yb = (unsigned char*)p.y;
   const int yrow = p.W * p.y_wmul;
-  if (wcol < p.W) {
+  const int wbase = w0 + 32 * wave;
 #pragma unroll
-    for (int hh = 0; hh < HT; ++hh) {
-      const int h = h0 + hh;
-      if (h < p.H) {
+  for (int hh = 0; hh < HT; ++hh) {
+    const int h = h0 + hh;
+    if (h < p.H) {                                  // block-uniform
 #pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) {
+      for (int cg = 0; cg < NCG; ++cg) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int co0 = cot * COT + cg * 32 + 8 * g + 4 * half;
-            const int vplane = co0 / EPR, within = co0 % EPR;
-            const int ygrp = vplane / p.y_gplanes;
-            const int yplane = vplane - ygrp * p.y_gplanes;
-            if (yplane < p.y_nplanes) {
-              float v[4];
+        for (int g = 0; g < 4; ++g) {
+          const int cl = cg * 32 + 8 * g + 4 * half;          // channel inside the tile
+          float v[4];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                v[i] = acc[hh][cg][4 * g + i];
-                if (p.bias) v[i] += p.bias[co0 + i];
-                if (p.relu) v[i] = fmaxf(v[i], 0.f);
-              }
-              const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
-                               (long)wcol * p.y_wmul + ygrp;
-              unsigned char* dst = yb + rec * 32 + within * sizeof(T);
-              if constexpr (sizeof(T) == 4) {
-                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-              } else {
-                __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
-                uint2 u;
-                u.x = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
-                u.y = (uint32_t)__builtin_bit_cast(unsigned short, b2) | ((uint32_t)__builtin_bit_cast(unsigned short, b3) << 16);
-                *(uint2*)dst = u;
-              }
-            }
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[hh][cg][4 * g + i];
+            if (p.bias) v[i] += p.bias[cot * COT + cl + i];
+            if (p.relu) v[i] = fmaxf(v[i], 0.f);
           }
+          unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
+          if constexpr (sizeof(T) == 4) {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
+            uint2 u;
+            u.x = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
+            u.y = (uint32_t)__builtin_bit_cast(unsigned short, b2) | ((uint32_t)__builtin_bit_cast(unsigned short, b3) << 16);
+            *(uint2*)dst = u;
+          }
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const int vplane = cot * NPL + pl;
+        const int ygrp = vplane / p.y_gplanes;
+        const int yplane = vplane - ygrp * p.y_gplanes;
+        const int px = lane >> 1, pc = lane & 1;
+        const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
+        if (yplane < p.y_nplanes && wbase + px < p.W) {
+          const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
+                           (long)(wbase + px) * p.y_wmul + ygrp;
+          *(uint4*)(yb + rec * 32 + 16 * pc) = val;
         }
       }
     }

@@ -144,8 +144,9 @@ class HipUNet(ParameterTree):
         """Name of the conv_igemm instantiation the library dispatches to (api.hip: run_igemm)."""
         kh, kw = self.kernel_size
         cot = 64 if hip.channel_pad(cout) % 64 == 0 else 32
-        ht = 6 if ((kh, kw) == (3, 5) and h % 6 == 0 and h % 5 != 0) else 5
-        return f"conv_igemm<{'bf16' if self.dtype == BF16 else 'f32'},{kh}x{kw},ht{ht},cot{cot}>"
+        ht = 3 if ((kh, kw) == (3, 5) and h % 3 == 0 and h % 5 != 0) else 5
+        t = 'bf16' if self.dtype == BF16 else 'f32'
+        return f"conv_igemm<{t},{kh}x{kw},ht{ht},cot{cot}>"
 
     def _conv(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1):
         if self.profile is not None and u.cin != 1:
