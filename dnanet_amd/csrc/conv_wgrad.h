@@ -18,6 +18,8 @@
 #pragma once
 #include "common.h"
 
+__device__ __attribute__((aligned(16))) const unsigned int dn_zero_page_wg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 struct WgradParams {
   const void* dy; int dy_pt, dy_p0, dy_nplanes, dy_gplanes, dy_wmul;
   const void* a;  int a_pt, a_p0, a_nplanes;
@@ -54,16 +56,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   constexpr bool KSPLIT = TAPS < 4;                         // waves split K steps instead of taps
   constexpr int WT = KSPLIT ? TAPS : (TAPS + 3) / 4;        // taps per wave
   constexpr int NK = 128 / KSTEP;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[DY_BYTES + A_BYTES];
+  constexpr int ST_ITERS = (DY_BYTES + A_BYTES + 4095) / 4096;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ST_ITERS * 4096];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int n_cit = p.ci_pad / CI_T, n_cot = p.co_pad / CO_T;
+  // tiles are the fast block index: blocks that run together walk the SAME strips (same split) for different
+  // (co, ci) tiles, so a strip is fetched from HBM about once per XCD L2 instead of once per tile
   int b = blockIdx.x;
-  const int split = b % p.nsplit; b /= p.nsplit;
-  const int cit = b % n_cit;
-  const int cot = b / n_cit;
-  (void)n_cot;
+  const int cit = b % n_cit; b /= n_cit;
+  const int cot = b % n_cot;
+  const int split = b / n_cot;
 
   f32x16_t acc[WT][NCOG][NCIG];
 #pragma unroll
@@ -79,48 +83,75 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   const unsigned char* ab = (const unsigned char*)p.a;
   const long dy_row = (long)p.W * p.dy_wmul;
 
+  // staging plan: LDS piece P = (it*4 + wave)*64 + lane of the linear image [dY planes | A planes] (plane strides
+  // padded, pad pieces are zero-filled).  st_off = byte offset of the source relative to the strip's base address,
+  // st_meta = column | row << 8 | isA << 12, or -1 for padding / absent planes.
+  int st_off[ST_ITERS], st_meta[ST_ITERS];
+#pragma unroll
+  for (int it = 0; it < ST_ITERS; ++it) {
+    const int byte = ((it * 4 + wave) * 64 + lane) * 16;
+    int off = 0, meta = -1;
+    if (byte < DY_BYTES) {
+      const int pl = byte / DY_PS, within = byte - pl * DY_PS;
+      if (within < DY_RAW) {
+        const int q = within >> 5, pc = (within >> 4) & 1;
+        const int vp = cot * CO_PL + pl;
+        const int grp = vp / p.dy_gplanes, plane = vp - grp * p.dy_gplanes;
+        if (plane < p.dy_nplanes) {
+          off = (int)((long)plane * p.H * dy_row * 32) + (q * p.dy_wmul + grp) * 32 + 16 * pc;
+          meta = q;
+        }
+      }
+    } else if (byte < DY_BYTES + A_BYTES) {
+      const int b2 = byte - DY_BYTES;
+      const int pl = b2 / A_PS, within = b2 - pl * A_PS;
+      if (within < A_RAW) {
+        const int rq = within >> 5, pc = (within >> 4) & 1;
+        const int row = rq / QW, q = rq - row * QW;
+        const int plane = cit * CI_PL + pl;
+        if (plane < p.a_nplanes) {
+          off = (int)((long)plane * p.H * p.W * 32) + ((row - PH) * p.W + (q - PW)) * 32 + 16 * pc;
+          meta = q | (row << 8) | (1 << 12);
+        }
+      }
+    }
+    st_off[it] = off;
+    st_meta[it] = meta;
+  }
+
   for (int strip = split; strip < p.nstrips; strip += p.nsplit) {
     const int tw = strip % p.ntw;
     const int h = (strip / p.ntw) % p.H;
     const int n = strip / (p.ntw * p.H);
     const int w0 = tw * 128;
     __syncthreads();
-    // ---- stage dY: CO_PL planes x 128 pixels
+#ifndef WG_ABLATE_NO_STAGE
+    // ---- stage dY (CO_PL planes x 128 px) and A (CI_PL planes x KH rows x QW px) straight into LDS with
+    // global_load_lds_dwordx4: every piece of the strip is in flight at once and costs no VGPRs.
+    {
+      const unsigned char* dy_base = dyb + (((long)(n * p.dy_pt + p.dy_p0) * p.H + h) * dy_row + (long)w0 * p.dy_wmul) * 32;
+      const unsigned char* a_base = ab + (((long)(n * p.a_pt + p.a_p0) * p.H + h) * p.W + w0) * 32;
 #pragma unroll
-    for (int it = 0; it < CO_PL; ++it) {
-      const int pl = it, q = tid >> 1, pc = tid & 1;
-      const int vp = cot * CO_PL + pl;
-      const int grp = vp / p.dy_gplanes, plane = vp - grp * p.dy_gplanes;
-      const int w = w0 + q;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (plane < p.dy_nplanes && w < p.W) {
-        const long rec = ((long)(n * p.dy_pt + p.dy_p0 + plane) * p.H + h) * dy_row + (long)w * p.dy_wmul + grp;
-        v = *(const uint4*)(dyb + rec * 32 + 16 * pc);
-      }
-      *(uint4*)(smem + pl * DY_PS + q * 32 + 16 * pc) = v;
-    }
-    // ---- stage A: CI_PL planes x KH rows x QW pixels
-    constexpr int A_PIECES = CI_PL * KH * QW * 2;
-#pragma unroll
-    for (int it = 0; it < (A_PIECES + 255) / 256; ++it) {
-      const int i = tid + it * 256;
-      const int pc = i & 1;
-      int r = i >> 1;
-      const int q = r % QW; r /= QW;
-      const int row = r % KH;
-      const int pl = r / KH;
-      const int plane = cit * CI_PL + pl;
-      const int hh = h + row - PH, w = w0 + q - PW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (i < A_PIECES) {
-        if (plane < p.a_nplanes && hh >= 0 && hh < p.H && w >= 0 && w < p.W) {
-          const long rec = ((long)(n * p.a_pt + p.a_p0 + plane) * p.H + hh) * p.W + w;
-          v = *(const uint4*)(ab + rec * 32 + 16 * pc);
+      for (int it = 0; it < ST_ITERS; ++it) {
+        const int meta = st_meta[it];
+        const unsigned char* src = (const unsigned char*)dn_zero_page_wg;
+        if (meta >= 0) {
+          const int q = meta & 0xff, row = (meta >> 8) & 0xf;
+          if (meta & (1 << 12)) {                       // A piece: image row h + row - PH, column w0 + q - PW
+            const int hh = h + row - PH, w = w0 + q - PW;
+            if (hh >= 0 && hh < p.H && w >= 0 && w < p.W) src = a_base + st_off[it];
+          } else if (w0 + q < p.W) {
+            src = dy_base + st_off[it];
+          }
         }
-        *(uint4*)(smem + DY_BYTES + pl * A_PS + (row * QW + q) * 32 + 16 * pc) = v;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (it * 4 + wave) * 1024), 16, 0, 0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
+#ifndef WG_ABLATE_NO_COMPUTE
     // ---- MFMA over the strip's pixels
     if constexpr (sizeof(T) == 2) {
       const int g = lane >> 4, idx = lane & 15;
@@ -185,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         }
       }
     }
+#endif
   }
 
   // ---- write this block's partial tile(s)
