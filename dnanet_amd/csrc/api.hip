@@ -35,6 +35,12 @@ static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t
   return dn_set_error(DN_ERR_UNSUPPORTED, "convolution kernel size (%d,%d) is not built (have (3,5), (1,3), (1,1))", kh, kw);
 }
 
+// A 1x1 GEMM has no halo, so the H x W pixels of a plane are one contiguous run: re-tile them as rows of 128
+// pixels so that 5-row tiles are always full (6 dye rows would otherwise leave a 1-row tile).
+static void flatten_rows(ConvParams& p) {
+  if (p.W % 128 == 0 && p.W > 128) { p.H = p.H * (p.W / 128); p.W = 128; }
+}
+
 extern "C" {
 
 const char* dn_last_error(void) { return g_err; }
@@ -72,6 +78,7 @@ int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2,
   p.w = packed_w; p.bias = bias2;
   p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = gsize / epr; p.y_wmul = 2;
   p.N = N; p.H = H; p.W = Win; p.nchunk = xp; p.cout_pad = 2 * gsize; p.relu = 0;
+  flatten_rows(p);
   return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);
 }
 
@@ -89,6 +96,7 @@ int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx
   p.w = packed_w; p.bias = nullptr;
   p.y = dx.base; p.y_planes_total = dx.planes_total; p.y_plane0 = dx.plane0; p.y_nplanes = xp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
   p.N = N; p.H = H; p.W = Win; p.nchunk = 2 * (gsize / epr); p.cout_pad = dn_channel_pad(dx.channels); p.relu = 0;
+  flatten_rows(p);
   return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);
 }
 
