@@ -252,7 +252,7 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   const long tiles = (long)(p.co_pad / TR::CO_T) * (p.ci_pad / TR::CI_T);
   const long per_slab = (long)TAPS * p.co_pad * p.ci_pad * 4 * (KSPLIT ? 4 : 1);
   long nsplit = std::max<long>(1, (1024 + tiles - 1) / tiles);
-  nsplit = std::min<long>(nsplit, p.nstrips);
+  nsplit = std::min<long>(nsplit, std::max<long>(1, p.nstrips / 16));   // >= 16 strips per block: slabs cost a round trip
   nsplit = std::min<long>(nsplit, slab_bytes / per_slab);
   if (nsplit < 1) return dn_set_error(DN_ERR_ARG, "conv_wgrad: workspace of %ld bytes is smaller than one partial slab (%ld)",
                                       slab_bytes, per_slab);

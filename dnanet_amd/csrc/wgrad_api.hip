@@ -27,9 +27,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       if (k < 2 && c < Cout && ci < Cin) dst = ((long)ci * Cout + c) * 2 + k;
     }
     if (dst < 0) continue;
+    // many slabs (small tensors): four independent chains keep loads in flight; fixed order => reproducible
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nslab; b += 4) {
+      s0 += slab[(long)b * per + i];
+      s1 += slab[(long)(b + 1) * per + i];
+      s2 += slab[(long)(b + 2) * per + i];
+      s3 += slab[(long)(b + 3) * per + i];
+    }
+    for (; b < nslab; ++b) s0 += slab[(long)b * per + i];
+    dw[dst] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+// Conv2d form with coalesced traffic on both sides: one block per (co, 64 input channels); slab reads run along
+// ci (256-byte runs), the sums are turned through LDS, and dw[co][ci0..ci0+63][taps] is written as one run.
+__global__ __launch_bounds__(256) void wgrad_reduce_conv_kernel(const float* __restrict__ slab, int nslab, int taps, int co_pad,
+                                                                int ci_pad, float* dw, int Cout, int Cin, int split, int half) {
+  __shared__ float tile[25 * 64];
+  const int nci = (ci_pad + 63) / 64;
+  const int co = blockIdx.x / nci, ci0 = (blockIdx.x % nci) * 64;
+  if (co >= Cout) return;
+  const long per = (long)taps * co_pad * ci_pad;
+  for (int e = threadIdx.x; e < taps * 64; e += 256) {
+    const int tap = e >> 6, cil = e & 63;
     float s = 0.f;
-    for (int b = 0; b < nslab; ++b) s += slab[(long)b * per + i];
-    dw[dst] = s;
+    if (ci0 + cil < ci_pad) {
+      const float* src = slab + ((long)tap * co_pad + co) * ci_pad + ci0 + cil;
+      for (int b = 0; b < nslab; ++b) s += src[(long)b * per];
+    }
+    tile[tap * 64 + cil] = s;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < taps * 64; o += 256) {
+    const int cil = o / taps, tap = o - cil * taps;
+    const int ci = ci0 + cil;
+    int cic = ci;
+    if (split > 0 && half != split) {               // concat input stored with padded halves
+      const int grp = ci / half, within = ci % half;
+      cic = (grp < 2 && within < split) ? grp * split + within : -1;
+    }
+    if (ci < ci_pad && cic >= 0 && cic < Cin) dw[((long)co * Cin + cic) * taps + tap] = tile[tap * 64 + cil];
   }
 }
 
@@ -73,9 +112,15 @@ int dn_conv2d_wgrad(dn_tensor dy, dn_tensor a, float* dw, void* workspace, long 
   int rc = run_wgrad(p, workspace_bytes, kh, kw, dtype, &nslab, (hipStream_t)stream);
   if (rc) return rc;
   const int half = concat_split > 0 ? dn_planes(concat_split, dtype) * epr : 0;
-  const long per = (long)kh * kw * p.co_pad * p.ci_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((per + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, nslab, kh * kw, p.co_pad, p.ci_pad, dw, dy.channels, cin, 0, concat_split, half, 1);
+  if (kh * kw <= 25 && nslab <= 64) {      // big tensors, few slabs: coalesced on both sides
+    const int nci = (p.ci_pad + 63) / 64;
+    hipLaunchKernelGGL(wgrad_reduce_conv_kernel, dim3((unsigned)(p.co_pad * nci)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, nslab, kh * kw, p.co_pad, p.ci_pad, dw, dy.channels, cin, concat_split, half);
+  } else {
+    const long per = (long)kh * kw * p.co_pad * p.ci_pad;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>((per + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, nslab, kh * kw, p.co_pad, p.ci_pad, dw, dy.channels, cin, 0, concat_split, half, 1);
+  }
   DN_LAUNCH_CHECK();
   return DN_OK;
 }
