@@ -10,15 +10,15 @@
 // fragment: bf16 fragments are fetched with the gfx950 transposing LDS read ds_read_b64_tr_b16
 // (4 pixels x 16 channels per 16-lane group, delivered channel-per-lane); fp32 fragments need one
 // value per lane (v_mfma_f32_32x32x2_f32) and use plain ds_read_b32.
-// Block = 4 waves, tile = CO_T x CI_T x all taps, K-loop over 128-column strips of one dye row
-// (plus KH-1 halo rows of A). Waves split the taps (3x5: 4/4/4/3); for kernels with < 4 taps they
-// split the K steps instead and write one partial slab each.
+// Block = 4 waves, tile = CO_T x CI_T x all taps, K-loop over SW-column strips of one dye row
+// (plus KH-1 halo rows of A), software pipelined through NBUF LDS buffers filled by LDS-DMA: strips s+1..
+// streams in while strip s feeds the MFMAs, one barrier per strip; two such workgroups share a CU.
+// Waves split the taps (3x5: 4/4/4/3); for kernels with < 4 taps they split the K steps instead and
+// write one partial slab each.
 // Split-K partials go to a slab [slab][tap][co_pad][ci_pad] that a second kernel sums in fixed order
 // (bitwise reproducible; no float atomics) and scatters into the canonical parameter layout.
 #pragma once
 #include "common.h"
-
-__device__ __attribute__((aligned(16))) const unsigned int dn_zero_page_wg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 struct WgradParams {
   const void* dy; int dy_pt, dy_p0, dy_nplanes, dy_gplanes, dy_wmul;
@@ -30,8 +30,34 @@ struct WgradParams {
 };
 
 template <typename T> struct WgTraits;
-template <> struct WgTraits<__bf16> { static constexpr int CO_T = 64, CI_T = 32, KSTEP = 16, BANKW = 256, PHASE = 128; };
-template <> struct WgTraits<float>  { static constexpr int CO_T = 32, CI_T = 32, KSTEP = 2,  BANKW = 128, PHASE = 32; };
+template <> struct WgTraits<__bf16> { static constexpr int CO_T = 64, CI_T = 32, KSTEP = 16, BANKW = 256, PHASE = 128, NBUF = 3; };
+template <> struct WgTraits<float>  { static constexpr int CO_T = 32, CI_T = 32, KSTEP = 2,  BANKW = 128, PHASE = 32, NBUF = 2; };
+
+#ifndef WG_STRIP
+#define WG_STRIP 64
+#endif
+
+// LDS-DMA from inline asm: hipcc neither drains nor counts it, so the prefetch of the next strips stays in flight
+// across the ds_reads of the current one; it is waited for by hand (s_waitcnt vmcnt).  Buffer addressing keeps the
+// per-strip VALU work at (almost) nothing -- a 64-bit per-lane address per 16-B piece costs more issue slots than
+// the MFMAs it feeds: address = SRD base (this image) + SGPR strip offset + per-lane offset fixed for the whole kernel,
+// and an offset >= num_records (WG_OOB) makes the hardware write zeros, which is how padding and halos are filled.
+#define WG_OOB 0x80000000u
+typedef __attribute__((ext_vector_type(4))) unsigned wg_srd_t;
+__device__ __forceinline__ wg_srd_t wg_make_srd(const void* base) {
+  const unsigned long long b = (unsigned long long)base;
+  wg_srd_t r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);   // stride 0: raw buffer
+  r.z = WG_OOB;                                                          // num_records (bytes)
+  r.w = 0x00020000u;                                                     // 32-bit untyped data format
+  return r;
+}
+__device__ __forceinline__ void wg_buffer_lds16(unsigned voff, wg_srd_t srd, unsigned soff, unsigned lds_addr_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr_uniform) : "memory");
+}
 
 __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
   typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -48,18 +74,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   constexpr int NCOG = CO_T / 32, NCIG = CI_T / 32;
   constexpr int CO_PL = CO_T / EPR, CI_PL = CI_T / EPR;     // planes per tile
   constexpr int PLG = 32 / EPR;                             // planes per 32-channel group
-  constexpr int QW = 128 + KW - 1;
-  constexpr int DY_RAW = 128 * 32, A_RAW = KH * QW * 32;
+  constexpr int SW = WG_STRIP;                              // strip width in pixels
+  constexpr int QW = SW + KW - 1;
+  constexpr int DY_RAW = SW * 32, A_RAW = KH * QW * 32;
   constexpr int DY_PS = DY_RAW + (TR::PHASE - DY_RAW % TR::BANKW + TR::BANKW) % TR::BANKW;   // plane strides chosen so the
   constexpr int A_PS = A_RAW + (TR::PHASE - A_RAW % TR::BANKW + TR::BANKW) % TR::BANKW;      // planes of one read hit distinct banks
-  constexpr int DY_BYTES = CO_PL * DY_PS, A_BYTES = CI_PL * A_PS;
+  constexpr int DY_BYTES = (CO_PL * DY_PS + 1023) / 1024 * 1024, A_BYTES = CI_PL * A_PS;   // dY region ends on a 1-KB piece boundary
   constexpr bool KSPLIT = TAPS < 4;                         // waves split K steps instead of taps
   constexpr int WT = KSPLIT ? TAPS : (TAPS + 3) / 4;        // taps per wave
-  constexpr int NK = 128 / KSTEP;
+  constexpr int NK = SW / KSTEP;
+  static_assert(!KSPLIT || NK % 4 == 0, "K steps must split over 4 waves");
   constexpr int ST_ITERS = (DY_BYTES + A_BYTES + 4095) / 4096;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[ST_ITERS * 4096];
+  constexpr int BUF_BYTES = ST_ITERS * 4096;
+  constexpr int NBUF = TR::NBUF;                            // strips in LDS: one being read, NBUF-1 in flight
+  static_assert((NBUF - 2) * ST_ITERS < 64, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_all[NBUF * BUF_BYTES];
+  const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int n_cit = p.ci_pad / CI_T, n_cot = p.co_pad / CO_T;
   // tiles are the fast block index: blocks that run together walk the SAME strips (same split) for different
@@ -83,22 +115,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   const unsigned char* ab = (const unsigned char*)p.a;
   const long dy_row = (long)p.W * p.dy_wmul;
 
+  // this wave's taps as byte offsets into an A plane image.  A wave with fewer real taps than WT (3x5: wave 3) repeats
+  // its last one into an accumulator that is never stored, which keeps the MFMA loop free of branches.
+  int tap_off[WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+    const int tap = KSPLIT ? i : min(wave + 4 * i, TAPS - 1);
+    const int dh = tap / KW, dw = tap - dh * KW;
+    tap_off[i] = __builtin_amdgcn_readfirstlane((dh * QW + dw) * 32);
+  }
+  // bf16 fragment addressing (ds_read_b64_tr_b16): 16-lane group g reads pixels 8*(g>>1).. of plane (g&1)
+  const int gpl_c = (lane >> 4) & 1;
+  const int frag_off = gpl_c * DY_PS + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + 8 * (lane & 3);
+  (void)frag_off;
+
   // staging plan: LDS piece P = (it*4 + wave)*64 + lane of the linear image [dY planes | A planes] (plane strides
-  // padded, pad pieces are zero-filled).  st_off = byte offset of the source relative to the strip's base address,
-  // st_meta = column | row << 8 | isA << 12, or -1 for padding / absent planes.
-  int st_off[ST_ITERS], st_meta[ST_ITERS];
+  // padded; pad pieces and absent planes are WG_OOB = zero-filled).  st_off = byte offset of the piece relative to
+  // the strip's origin -- dY: (row h, column w0) of the image's first plane; A: (row h-PH, column w0-PW) --
+  // st_meta = column | row << 8 | isA << 12 for the border checks, or -1.
+  unsigned st_off[ST_ITERS];
+  int st_meta[ST_ITERS];
 #pragma unroll
   for (int it = 0; it < ST_ITERS; ++it) {
     const int byte = ((it * 4 + wave) * 64 + lane) * 16;
-    int off = 0, meta = -1;
+    unsigned off = WG_OOB;
+    int meta = -1;
     if (byte < DY_BYTES) {
       const int pl = byte / DY_PS, within = byte - pl * DY_PS;
-      if (within < DY_RAW) {
+      if (pl < CO_PL && within < DY_RAW) {
         const int q = within >> 5, pc = (within >> 4) & 1;
         const int vp = cot * CO_PL + pl;
         const int grp = vp / p.dy_gplanes, plane = vp - grp * p.dy_gplanes;
         if (plane < p.dy_nplanes) {
-          off = (int)((long)plane * p.H * dy_row * 32) + (q * p.dy_wmul + grp) * 32 + 16 * pc;
+          off = (unsigned)(((long)plane * p.H * dy_row + q * p.dy_wmul + grp) * 32 + 16 * pc);
           meta = q;
         }
       }
@@ -110,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int row = rq / QW, q = rq - row * QW;
         const int plane = cit * CI_PL + pl;
         if (plane < p.a_nplanes) {
-          off = (int)((long)plane * p.H * p.W * 32) + ((row - PH) * p.W + (q - PW)) * 32 + 16 * pc;
+          off = (unsigned)(((long)plane * p.H * p.W + row * p.W + q) * 32 + 16 * pc);
           meta = q | (row << 8) | (1 << 12);
         }
       }
@@ -119,77 +168,96 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     st_meta[it] = meta;
   }
 
-  for (int strip = split; strip < p.nstrips; strip += p.nsplit) {
+  auto stage = [&](int strip, int buf) {
     const int tw = strip % p.ntw;
     const int h = (strip / p.ntw) % p.H;
     const int n = strip / (p.ntw * p.H);
-    const int w0 = tw * 128;
-    __syncthreads();
-#ifndef WG_ABLATE_NO_STAGE
-    // ---- stage dY (CO_PL planes x 128 px) and A (CI_PL planes x KH rows x QW px) straight into LDS with
-    // global_load_lds_dwordx4: every piece of the strip is in flight at once and costs no VGPRs.
-    {
-      const unsigned char* dy_base = dyb + (((long)(n * p.dy_pt + p.dy_p0) * p.H + h) * dy_row + (long)w0 * p.dy_wmul) * 32;
-      const unsigned char* a_base = ab + (((long)(n * p.a_pt + p.a_p0) * p.H + h) * p.W + w0) * 32;
+    const int w0 = tw * SW;
+    const wg_srd_t srd_dy = wg_make_srd(dyb + (long)(n * p.dy_pt + p.dy_p0) * p.H * dy_row * 32);
+    const wg_srd_t srd_a = wg_make_srd(ab + (long)(n * p.a_pt + p.a_p0) * p.H * p.W * 32);
+    const unsigned so_dy = (unsigned)(((long)h * dy_row + (long)w0 * p.dy_wmul) * 32);
+    const unsigned so_a = (unsigned)((((long)h - PH) * p.W + (w0 - PW)) * 32);   // wraps at the top/left border: checked path only
+    const bool interior = h >= PH && h + (KH - 1 - PH) < p.H && w0 >= PW && w0 + SW + (KW - 1 - PW) <= p.W;
+    const unsigned lds0 = smem_lds + buf * BUF_BYTES + wave * 1024;
+    if (interior) {
 #pragma unroll
       for (int it = 0; it < ST_ITERS; ++it) {
+        const bool is_a = (it * 4 + wave) * 1024 >= DY_BYTES;          // wave-uniform
+        wg_buffer_lds16(st_off[it], is_a ? srd_a : srd_dy, is_a ? so_a : so_dy,
+                        __builtin_amdgcn_readfirstlane(lds0 + it * 4096));
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < ST_ITERS; ++it) {
+        const bool is_a = (it * 4 + wave) * 1024 >= DY_BYTES;
         const int meta = st_meta[it];
-        const unsigned char* src = (const unsigned char*)dn_zero_page_wg;
-        if (meta >= 0) {
-          const int q = meta & 0xff, row = (meta >> 8) & 0xf;
-          if (meta & (1 << 12)) {                       // A piece: image row h + row - PH, column w0 + q - PW
-            const int hh = h + row - PH, w = w0 + q - PW;
-            if (hh >= 0 && hh < p.H && w >= 0 && w < p.W) src = a_base + st_off[it];
-          } else if (w0 + q < p.W) {
-            src = dy_base + st_off[it];
-          }
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + (it * 4 + wave) * 1024), 16, 0, 0);
+        const int q = meta & 0xff, row = (meta >> 8) & 0xf;
+        const bool ok = is_a ? ((unsigned)(h + row - PH) < (unsigned)p.H && (unsigned)(w0 + q - PW) < (unsigned)p.W)
+                             : (w0 + q < p.W);
+        const unsigned off = (meta >= 0 && ok) ? st_off[it] + (is_a ? so_a : so_dy) : WG_OOB;
+        wg_buffer_lds16(off, is_a ? srd_a : srd_dy, 0u, __builtin_amdgcn_readfirstlane(lds0 + it * 4096));
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // LDS-DMA completes in issue order, so "at most (NBUF-2)*ST_ITERS of my loads outstanding" means the oldest
+  // strip in flight has landed
+  int buf = 0;
+#ifndef WG_ABLATE_NO_STAGE
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i)
+    if (split + i * p.nsplit < p.nstrips) stage(split + i * p.nsplit, i);
 #endif
-    __syncthreads();
+  for (int strip = split; strip < p.nstrips; strip += p.nsplit, buf = buf + 1 == NBUF ? 0 : buf + 1) {
+    if (strip + (NBUF - 2) * p.nsplit < p.nstrips) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ST_ITERS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // everyone's pieces landed; everyone left the oldest buffer
+#ifndef WG_ABLATE_NO_STAGE
+    if (strip + (NBUF - 1) * p.nsplit < p.nstrips)
+      stage(strip + (NBUF - 1) * p.nsplit, buf == 0 ? NBUF - 1 : buf - 1);
+#endif
+    const unsigned char* smem = smem_all + buf * BUF_BYTES;
+    (void)smem;
 #ifndef WG_ABLATE_NO_COMPUTE
     // ---- MFMA over the strip's pixels
     if constexpr (sizeof(T) == 2) {
-      const int g = lane >> 4, idx = lane & 15;
-      const int toff = (8 * (g >> 1) + (idx >> 2)) * 32 + 8 * (idx & 3);   // pixel (8*khalf + q), columns 4p..4p+3
-      const int gpl = g & 1;
-#pragma unroll 2
-      for (int ks0 = 0; ks0 < NK; ks0 += (KSPLIT ? 4 : 1)) {
-        const int ks = KSPLIT ? ks0 + wave : ks0;
-        uint4 af[NCOG];
+      // register double buffering: the fragments of K step it+1 are read while the MFMAs of step it run
+      constexpr int NIT = KSPLIT ? NK / 4 : NK;
+      auto load_frags = [&](int it, uint4 (&af)[NCOG], uint4 (&bf)[WT][NCIG]) {
+        const int ks = KSPLIT ? it * 4 + wave : it;
+        const unsigned char* kbase = smem + ks * 16 * 32 + frag_off;
 #pragma unroll
         for (int cg = 0; cg < NCOG; ++cg) {
-          const unsigned char* base = smem + (cg * PLG + gpl) * DY_PS + ks * 16 * 32 + toff;
+          const unsigned char* base = kbase + cg * PLG * DY_PS;
           const uint2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * 32);
           af[cg] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
 #pragma unroll
-        for (int i = 0; i < WT; ++i) {
-          const int tap = KSPLIT ? i : wave + 4 * i;
-          if (tap < TAPS) {
-            const int dh = tap / KW, dw = tap - dh * KW;
-            uint4 bf[NCIG];
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int cg = 0; cg < NCIG; ++cg) {
-              const unsigned char* base = smem + DY_BYTES + (cg * PLG + gpl) * A_PS + (dh * QW + ks * 16 + dw) * 32 + toff;
-              const uint2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * 32);
-              bf[cg] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-#pragma unroll
-            for (int a = 0; a < NCOG; ++a)
-#pragma unroll
-              for (int c = 0; c < NCIG; ++c)
-                acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[a]),
-                                                                       __builtin_bit_cast(bf16x8_t, bf[c]), acc[i][a][c], 0, 0, 0);
+          for (int cg = 0; cg < NCIG; ++cg) {
+            const unsigned char* base = kbase + DY_BYTES + (A_PS - DY_PS) * gpl_c + cg * PLG * A_PS + tap_off[i];
+            const uint2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * 32);
+            bf[i][cg] = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
-        }
+      };
+      uint4 af[2][NCOG], bf[2][WT][NCIG];
+      load_frags(0, af[0], bf[0]);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (it + 1 < NIT) load_frags(it + 1, af[(it + 1) & 1], bf[(it + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int a = 0; a < NCOG; ++a)
+#pragma unroll
+            for (int c = 0; c < NCIG; ++c)
+              acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[it & 1][a]),
+                                                                     __builtin_bit_cast(bf16x8_t, bf[it & 1][i][c]),
+                                                                     acc[i][a][c], 0, 0, 0);
       }
     } else {
-      const int foff = (l31 >> 3) * 0 + (l31 & 7) * 4;   // channel inside its plane
+      const int foff = (l31 & 7) * 4;                    // channel inside its plane
       const int fpl = l31 >> 3;
 #pragma unroll 4
       for (int ks0 = 0; ks0 < NK; ks0 += (KSPLIT ? 4 : 1)) {
@@ -198,22 +266,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         float af[NCOG];
 #pragma unroll
         for (int cg = 0; cg < NCOG; ++cg) af[cg] = *(const float*)(smem + (cg * PLG + fpl) * DY_PS + px * 32 + foff);
+        float bf[WT][NCIG];
 #pragma unroll
-        for (int i = 0; i < WT; ++i) {
-          const int tap = KSPLIT ? i : wave + 4 * i;
-          if (tap < TAPS) {
-            const int dh = tap / KW, dw = tap - dh * KW;
-            float bf[NCIG];
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int cg = 0; cg < NCIG; ++cg)
-              bf[cg] = *(const float*)(smem + DY_BYTES + (cg * PLG + fpl) * A_PS + (dh * QW + px + dw) * 32 + foff);
+          for (int cg = 0; cg < NCIG; ++cg)
+            bf[i][cg] = *(const float*)(smem + DY_BYTES + (cg * PLG + fpl) * A_PS + tap_off[i] + px * 32 + foff);
 #pragma unroll
-            for (int a = 0; a < NCOG; ++a)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-              for (int c = 0; c < NCIG; ++c)
-                acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[c], acc[i][a][c], 0, 0, 0);
-          }
-        }
+          for (int a = 0; a < NCOG; ++a)
+#pragma unroll
+            for (int c = 0; c < NCIG; ++c)
+              acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[i][c], acc[i][a][c], 0, 0, 0);
       }
     }
 #endif
@@ -245,7 +310,9 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   using TR = WgTraits<T>;
   constexpr int TAPS = KH * KW;
   constexpr bool KSPLIT = TAPS < 4;
-  p.ntw = (p.W + 127) / 128;
+  p.ntw = (p.W + WG_STRIP - 1) / WG_STRIP;
+  if ((long)p.dy_pt * p.H * p.W * p.dy_wmul * 32 >= (1L << 31) || (long)p.a_pt * p.H * p.W * 32 >= (1L << 31))
+    return dn_set_error(DN_ERR_ARG, "conv_wgrad: one image of an operand exceeds 2 GiB (32-bit buffer offsets)");
   p.nstrips = p.N * p.H * p.ntw;
   p.co_pad = (p.co_pad + TR::CO_T - 1) / TR::CO_T * TR::CO_T;
   p.ci_pad = (p.ci_pad + TR::CI_T - 1) / TR::CI_T * TR::CI_T;
