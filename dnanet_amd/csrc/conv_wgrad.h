@@ -26,22 +26,24 @@ struct WgradParams {
   float* slab;
   int N, H, W;
   int co_pad, ci_pad;
-  int nsplit, nstrips, ntw;
+  int nsplit, nstrips, ntw, nth;
 };
 
 template <typename T> struct WgTraits;
-template <> struct WgTraits<__bf16> { static constexpr int CO_T = 64, CI_T = 32, KSTEP = 16, BANKW = 256, PHASE = 128, NBUF = 3; };
-template <> struct WgTraits<float>  { static constexpr int CO_T = 32, CI_T = 32, KSTEP = 2,  BANKW = 128, PHASE = 32, NBUF = 2; };
+template <> struct WgTraits<__bf16> { static constexpr int CO_T = 64, CI_T = 32, KSTEP = 16, BANKW = 256, PHASE = 128; };
+template <> struct WgTraits<float>  { static constexpr int CO_T = 32, CI_T = 32, KSTEP = 2,  BANKW = 128, PHASE = 32; };
 
-#ifndef WG_STRIP
-#define WG_STRIP 64
-#endif
+// strip = HT dye rows x SW scan columns of one image.  Row tiles (HT > 1) exist for the 3-row kernels: the KH-1 halo
+// rows of A are then fetched once per HT output rows instead of once per row, which is what moves the kernel from
+// the L2 bandwidth bound to the MFMA bound (bytes staged per flop: x0.6 at HT = 5).
+template <typename T> constexpr int wg_strip_width(int ht) { return ht == 1 ? 64 : (sizeof(T) == 2 ? 32 : 16); }
 
 // LDS-DMA from inline asm: hipcc neither drains nor counts it, so the prefetch of the next strips stays in flight
 // across the ds_reads of the current one; it is waited for by hand (s_waitcnt vmcnt).  Buffer addressing keeps the
-// per-strip VALU work at (almost) nothing -- a 64-bit per-lane address per 16-B piece costs more issue slots than
-// the MFMAs it feeds: address = SRD base (this image) + SGPR strip offset + per-lane offset fixed for the whole kernel,
-// and an offset >= num_records (WG_OOB) makes the hardware write zeros, which is how padding and halos are filled.
+// per-strip VALU work small -- a 64-bit per-lane address and a zero-page select per 16-B piece cost more issue slots
+// than the MFMAs they feed: address = SRD base (this image) + 32-bit (per-lane offset fixed for the whole kernel +
+// uniform strip offset), and an offset >= num_records (WG_OOB) makes the hardware write zeros, which is how padding,
+// halos and image borders are filled.
 #define WG_OOB 0x80000000u
 typedef __attribute__((ext_vector_type(4))) unsigned wg_srd_t;
 __device__ __forceinline__ wg_srd_t wg_make_srd(const void* base) {
@@ -53,10 +55,10 @@ __device__ __forceinline__ wg_srd_t wg_make_srd(const void* base) {
   r.w = 0x00020000u;                                                     // 32-bit untyped data format
   return r;
 }
-__device__ __forceinline__ void wg_buffer_lds16(unsigned voff, wg_srd_t srd, unsigned soff, unsigned lds_addr_uniform) {
+__device__ __forceinline__ void wg_buffer_lds16(unsigned voff, wg_srd_t srd, unsigned lds_addr_uniform) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(soff), "s"(lds_addr_uniform) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr_uniform) : "memory");
 }
 
 __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
@@ -65,7 +67,7 @@ __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int KH, int KW>
+template <typename T, int KH, int KW, int HT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
   using TR = WgTraits<T>;
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
@@ -74,19 +76,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   constexpr int NCOG = CO_T / 32, NCIG = CI_T / 32;
   constexpr int CO_PL = CO_T / EPR, CI_PL = CI_T / EPR;     // planes per tile
   constexpr int PLG = 32 / EPR;                             // planes per 32-channel group
-  constexpr int SW = WG_STRIP;                              // strip width in pixels
-  constexpr int QW = SW + KW - 1;
-  constexpr int DY_RAW = SW * 32, A_RAW = KH * QW * 32;
+  constexpr int SW = wg_strip_width<T>(HT);                 // strip width in pixels
+  constexpr int QW = SW + KW - 1, AR = HT + KH - 1;         // A image: AR rows x QW columns per plane
+  constexpr int DY_RAW = HT * SW * 32, A_RAW = AR * QW * 32;
   constexpr int DY_PS = DY_RAW + (TR::PHASE - DY_RAW % TR::BANKW + TR::BANKW) % TR::BANKW;   // plane strides chosen so the
   constexpr int A_PS = A_RAW + (TR::PHASE - A_RAW % TR::BANKW + TR::BANKW) % TR::BANKW;      // planes of one read hit distinct banks
   constexpr int DY_BYTES = (CO_PL * DY_PS + 1023) / 1024 * 1024, A_BYTES = CI_PL * A_PS;   // dY region ends on a 1-KB piece boundary
   constexpr bool KSPLIT = TAPS < 4;                         // waves split K steps instead of taps
   constexpr int WT = KSPLIT ? TAPS : (TAPS + 3) / 4;        // taps per wave
-  constexpr int NK = SW / KSTEP;
-  static_assert(!KSPLIT || NK % 4 == 0, "K steps must split over 4 waves");
+  constexpr int NK = SW / KSTEP;                            // K steps per row of the strip
+  static_assert(!KSPLIT || (HT == 1 && NK % 4 == 0), "K steps must split over 4 waves");
   constexpr int ST_ITERS = (DY_BYTES + A_BYTES + 4095) / 4096;
   constexpr int BUF_BYTES = ST_ITERS * 4096;
-  constexpr int NBUF = TR::NBUF;                            // strips in LDS: one being read, NBUF-1 in flight
+  constexpr int NBUF = 2 * 3 * BUF_BYTES <= 160 * 1024 ? 3 : 2;   // strips in LDS: one being read, NBUF-1 in flight
+  static_assert(2 * NBUF * BUF_BYTES <= 160 * 1024, "two workgroups per CU");
   static_assert((NBUF - 2) * ST_ITERS < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(16))) unsigned char smem_all[NBUF * BUF_BYTES];
   const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all);
@@ -130,74 +133,78 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   (void)frag_off;
 
   // staging plan: LDS piece P = (it*4 + wave)*64 + lane of the linear image [dY planes | A planes] (plane strides
-  // padded; pad pieces and absent planes are WG_OOB = zero-filled).  st_off = byte offset of the piece relative to
-  // the strip's origin -- dY: (row h, column w0) of the image's first plane; A: (row h-PH, column w0-PW) --
-  // st_meta = column | row << 8 | isA << 12 for the border checks, or -1.
+  // padded; pad pieces and absent planes are zero-filled).  st_off = byte offset of the piece relative to (row h0,
+  // column w0) of the image's first plane, st_row / st_col = its row and column relative to (h0, w0) for the image
+  // border checks (the halo makes them negative; a piece that never exists gets a row no image has).
   unsigned st_off[ST_ITERS];
-  int st_meta[ST_ITERS];
+  int st_row[ST_ITERS], st_col[ST_ITERS];
 #pragma unroll
   for (int it = 0; it < ST_ITERS; ++it) {
     const int byte = ((it * 4 + wave) * 64 + lane) * 16;
-    unsigned off = WG_OOB;
-    int meta = -1;
+    unsigned off = 0;
+    int row = 1 << 30, col = 0;
     if (byte < DY_BYTES) {
       const int pl = byte / DY_PS, within = byte - pl * DY_PS;
       if (pl < CO_PL && within < DY_RAW) {
-        const int q = within >> 5, pc = (within >> 4) & 1;
+        const int rec = within >> 5, pc = (within >> 4) & 1;
+        const int r = rec / SW, q = rec - r * SW;
         const int vp = cot * CO_PL + pl;
         const int grp = vp / p.dy_gplanes, plane = vp - grp * p.dy_gplanes;
         if (plane < p.dy_nplanes) {
-          off = (unsigned)(((long)plane * p.H * dy_row + q * p.dy_wmul + grp) * 32 + 16 * pc);
-          meta = q;
+          off = (unsigned)((((long)plane * p.H + r) * dy_row + q * p.dy_wmul + grp) * 32 + 16 * pc);
+          row = r; col = q;
         }
       }
     } else if (byte < DY_BYTES + A_BYTES) {
       const int b2 = byte - DY_BYTES;
       const int pl = b2 / A_PS, within = b2 - pl * A_PS;
       if (within < A_RAW) {
-        const int rq = within >> 5, pc = (within >> 4) & 1;
-        const int row = rq / QW, q = rq - row * QW;
+        const int rec = within >> 5, pc = (within >> 4) & 1;
+        const int r = rec / QW, q = rec - r * QW;
         const int plane = cit * CI_PL + pl;
         if (plane < p.a_nplanes) {
-          off = (unsigned)(((long)plane * p.H * p.W + row * p.W + q) * 32 + 16 * pc);
-          meta = q | (row << 8) | (1 << 12);
+          off = (unsigned)((((long)plane * p.H + (r - PH)) * p.W + (q - PW)) * 32 + 16 * pc);   // may wrap; the sum below does not
+          row = r - PH; col = q - PW;
         }
       }
     }
-    st_off[it] = off;
-    st_meta[it] = meta;
+    st_off[it] = off; st_row[it] = row; st_col[it] = col;
   }
 
-  auto stage = [&](int strip, int buf) {
+  // staging of one strip = uniform set-up (SALU) + ST_ITERS independent pieces, so that the pieces of the next strip
+  // can be sprinkled between the MFMAs of the current one instead of stalling the matrix pipe in one burst
+  struct StageCtx { wg_srd_t srd_dy, srd_a; unsigned so_dy, so_a, lds0; int h0, w0; };
+  auto stage_begin = [&](int strip, int buf) {
+    StageCtx c;
     const int tw = strip % p.ntw;
-    const int h = (strip / p.ntw) % p.H;
-    const int n = strip / (p.ntw * p.H);
-    const int w0 = tw * SW;
-    const wg_srd_t srd_dy = wg_make_srd(dyb + (long)(n * p.dy_pt + p.dy_p0) * p.H * dy_row * 32);
-    const wg_srd_t srd_a = wg_make_srd(ab + (long)(n * p.a_pt + p.a_p0) * p.H * p.W * 32);
-    const unsigned so_dy = (unsigned)(((long)h * dy_row + (long)w0 * p.dy_wmul) * 32);
-    const unsigned so_a = (unsigned)((((long)h - PH) * p.W + (w0 - PW)) * 32);   // wraps at the top/left border: checked path only
-    const bool interior = h >= PH && h + (KH - 1 - PH) < p.H && w0 >= PW && w0 + SW + (KW - 1 - PW) <= p.W;
-    const unsigned lds0 = smem_lds + buf * BUF_BYTES + wave * 1024;
-    if (interior) {
+    const int n = strip / (p.ntw * p.nth);
+    c.h0 = (strip / p.ntw) % p.nth * HT;
+    c.w0 = tw * SW;
+    c.srd_dy = wg_make_srd(dyb + (long)(n * p.dy_pt + p.dy_p0) * p.H * dy_row * 32);
+    c.srd_a = wg_make_srd(ab + (long)(n * p.a_pt + p.a_p0) * p.H * p.W * 32);
+    c.so_dy = (unsigned)(((long)c.h0 * dy_row + (long)c.w0 * p.dy_wmul) * 32);
+    c.so_a = (unsigned)(((long)c.h0 * p.W + c.w0) * 32);
+    c.lds0 = smem_lds + buf * BUF_BYTES + wave * 1024;
+    return c;
+  };
+  auto stage_piece = [&](const StageCtx& c, int it) {
+    const bool is_a = (it * 4 + wave) * 1024 >= DY_BYTES;              // wave-uniform
+    const bool ok = ((unsigned)(c.h0 + st_row[it]) < (unsigned)p.H) & ((unsigned)(c.w0 + st_col[it]) < (unsigned)p.W);
+    const unsigned off = ok ? st_off[it] + (is_a ? c.so_a : c.so_dy) : WG_OOB;
+    wg_buffer_lds16(off, is_a ? c.srd_a : c.srd_dy, __builtin_amdgcn_readfirstlane(c.lds0 + it * 4096));
+  };
+  // a strip past the end is still "staged", with every offset out of range (zeros into a buffer nobody reads): the
+  // loops stay branch-free and the vmcnt arithmetic is the same for every strip
+  auto stage_begin_checked = [&](int strip, int buf) {
+    const bool exists = strip < p.nstrips;
+    StageCtx c = stage_begin(exists ? strip : 0, buf);
+    if (!exists) c.h0 = 1 << 29;
+    return c;
+  };
+  auto stage = [&](int strip, int buf) {
+    const StageCtx c = stage_begin_checked(strip, buf);
 #pragma unroll
-      for (int it = 0; it < ST_ITERS; ++it) {
-        const bool is_a = (it * 4 + wave) * 1024 >= DY_BYTES;          // wave-uniform
-        wg_buffer_lds16(st_off[it], is_a ? srd_a : srd_dy, is_a ? so_a : so_dy,
-                        __builtin_amdgcn_readfirstlane(lds0 + it * 4096));
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < ST_ITERS; ++it) {
-        const bool is_a = (it * 4 + wave) * 1024 >= DY_BYTES;
-        const int meta = st_meta[it];
-        const int q = meta & 0xff, row = (meta >> 8) & 0xf;
-        const bool ok = is_a ? ((unsigned)(h + row - PH) < (unsigned)p.H && (unsigned)(w0 + q - PW) < (unsigned)p.W)
-                             : (w0 + q < p.W);
-        const unsigned off = (meta >= 0 && ok) ? st_off[it] + (is_a ? so_a : so_dy) : WG_OOB;
-        wg_buffer_lds16(off, is_a ? srd_a : srd_dy, 0u, __builtin_amdgcn_readfirstlane(lds0 + it * 4096));
-      }
-    }
+    for (int it = 0; it < ST_ITERS; ++it) stage_piece(c, it);
   };
 
   // LDS-DMA completes in issue order, so "at most (NBUF-2)*ST_ITERS of my loads outstanding" means the oldest
@@ -206,15 +213,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #ifndef WG_ABLATE_NO_STAGE
 #pragma unroll
   for (int i = 0; i < NBUF - 1; ++i)
-    if (split + i * p.nsplit < p.nstrips) stage(split + i * p.nsplit, i);
+    stage(split + i * p.nsplit, i);
 #endif
   for (int strip = split; strip < p.nstrips; strip += p.nsplit, buf = buf + 1 == NBUF ? 0 : buf + 1) {
-    if (strip + (NBUF - 2) * p.nsplit < p.nstrips) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ST_ITERS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ST_ITERS) : "memory");
     __syncthreads();                                    // everyone's pieces landed; everyone left the oldest buffer
+    const int nxt_strip = strip + (NBUF - 1) * p.nsplit, nxt_buf = buf == 0 ? NBUF - 1 : buf - 1;
+    (void)nxt_strip; (void)nxt_buf;
 #ifndef WG_ABLATE_NO_STAGE
-    if (strip + (NBUF - 1) * p.nsplit < p.nstrips)
-      stage(strip + (NBUF - 1) * p.nsplit, buf == 0 ? NBUF - 1 : buf - 1);
+    if (sizeof(T) != 2) stage(nxt_strip, nxt_buf);
 #endif
     const unsigned char* smem = smem_all + buf * BUF_BYTES;
     (void)smem;
@@ -222,13 +229,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     // ---- MFMA over the strip's pixels
     if constexpr (sizeof(T) == 2) {
       // register double buffering: the fragments of K step it+1 are read while the MFMAs of step it run
-      constexpr int NIT = KSPLIT ? NK / 4 : NK;
+      constexpr int NIT = KSPLIT ? NK / 4 : HT * NK;
       auto load_frags = [&](int it, uint4 (&af)[NCOG], uint4 (&bf)[WT][NCIG]) {
-        const int ks = KSPLIT ? it * 4 + wave : it;
-        const unsigned char* kbase = smem + ks * 16 * 32 + frag_off;
+        const int r = KSPLIT ? 0 : it / NK;
+        const int ks = KSPLIT ? it * 4 + wave : it - r * NK;
+        const unsigned char* dbase = smem + frag_off + (r * SW + ks * 16) * 32;
+        const unsigned char* abase = smem + frag_off + DY_BYTES + (A_PS - DY_PS) * gpl_c + (r * QW + ks * 16) * 32;
 #pragma unroll
         for (int cg = 0; cg < NCOG; ++cg) {
-          const unsigned char* base = kbase + cg * PLG * DY_PS;
+          const unsigned char* base = dbase + cg * PLG * DY_PS;
           const uint2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * 32);
           af[cg] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
@@ -236,16 +245,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         for (int i = 0; i < WT; ++i)
 #pragma unroll
           for (int cg = 0; cg < NCIG; ++cg) {
-            const unsigned char* base = kbase + DY_BYTES + (A_PS - DY_PS) * gpl_c + cg * PLG * A_PS + tap_off[i];
+            const unsigned char* base = abase + cg * PLG * A_PS + tap_off[i];
             const uint2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * 32);
             bf[i][cg] = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
       };
+      constexpr int PPI = (ST_ITERS + NIT - 1) / NIT;   // pieces of the next strip staged per K step
       uint4 af[2][NCOG], bf[2][WT][NCIG];
       load_frags(0, af[0], bf[0]);
+#ifndef WG_ABLATE_NO_STAGE
+      const StageCtx sc = stage_begin_checked(nxt_strip, nxt_buf);
+#endif
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         if (it + 1 < NIT) load_frags(it + 1, af[(it + 1) & 1], bf[(it + 1) & 1]);
+#ifndef WG_ABLATE_NO_STAGE
+#pragma unroll
+        for (int k = it * PPI; k < (it + 1) * PPI && k < ST_ITERS; ++k) stage_piece(sc, k);
+#endif
 #pragma unroll
         for (int i = 0; i < WT; ++i)
 #pragma unroll
@@ -259,31 +276,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     } else {
       const int foff = (l31 & 7) * 4;                    // channel inside its plane
       const int fpl = l31 >> 3;
+#pragma unroll
+      for (int r = 0; r < HT; ++r) {
 #pragma unroll 4
-      for (int ks0 = 0; ks0 < NK; ks0 += (KSPLIT ? 4 : 1)) {
-        const int ks = KSPLIT ? ks0 + wave : ks0;
-        const int px = ks * 2 + half;
-        float af[NCOG];
+        for (int ks0 = 0; ks0 < NK; ks0 += (KSPLIT ? 4 : 1)) {
+          const int ks = KSPLIT ? ks0 + wave : ks0;
+          const int px = ks * 2 + half;
+          float af[NCOG];
 #pragma unroll
-        for (int cg = 0; cg < NCOG; ++cg) af[cg] = *(const float*)(smem + (cg * PLG + fpl) * DY_PS + px * 32 + foff);
-        float bf[WT][NCIG];
+          for (int cg = 0; cg < NCOG; ++cg)
+            af[cg] = *(const float*)(smem + (cg * PLG + fpl) * DY_PS + (r * SW + px) * 32 + foff);
+          float bf[WT][NCIG];
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+          for (int i = 0; i < WT; ++i)
 #pragma unroll
-          for (int cg = 0; cg < NCIG; ++cg)
-            bf[i][cg] = *(const float*)(smem + DY_BYTES + (cg * PLG + fpl) * A_PS + tap_off[i] + px * 32 + foff);
+            for (int cg = 0; cg < NCIG; ++cg)
+              bf[i][cg] = *(const float*)(smem + DY_BYTES + (cg * PLG + fpl) * A_PS + tap_off[i] + (r * QW + px) * 32 + foff);
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+          for (int i = 0; i < WT; ++i)
 #pragma unroll
-          for (int a = 0; a < NCOG; ++a)
+            for (int a = 0; a < NCOG; ++a)
 #pragma unroll
-            for (int c = 0; c < NCIG; ++c)
-              acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[i][c], acc[i][a][c], 0, 0, 0);
+              for (int c = 0; c < NCIG; ++c)
+                acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[i][c], acc[i][a][c], 0, 0, 0);
+        }
       }
     }
 #endif
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
   // ---- write this block's partial tile(s)
   const int slab_idx = KSPLIT ? split * 4 + wave : split;
   float* slab = p.slab + (long)slab_idx * TAPS * p.co_pad * p.ci_pad;
@@ -305,27 +327,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   }
 }
 
-template <typename T, int KH, int KW>
+template <typename T, int KH, int KW, int HT = 1>
 int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_t stream) {
   using TR = WgTraits<T>;
   constexpr int TAPS = KH * KW;
   constexpr bool KSPLIT = TAPS < 4;
-  p.ntw = (p.W + WG_STRIP - 1) / WG_STRIP;
+  constexpr int SW = wg_strip_width<T>(HT);
+  p.ntw = (p.W + SW - 1) / SW;
+  p.nth = (p.H + HT - 1) / HT;
   if ((long)p.dy_pt * p.H * p.W * p.dy_wmul * 32 >= (1L << 31) || (long)p.a_pt * p.H * p.W * 32 >= (1L << 31))
     return dn_set_error(DN_ERR_ARG, "conv_wgrad: one image of an operand exceeds 2 GiB (32-bit buffer offsets)");
-  p.nstrips = p.N * p.H * p.ntw;
+  p.nstrips = p.N * p.nth * p.ntw;
   p.co_pad = (p.co_pad + TR::CO_T - 1) / TR::CO_T * TR::CO_T;
   p.ci_pad = (p.ci_pad + TR::CI_T - 1) / TR::CI_T * TR::CI_T;
   const long tiles = (long)(p.co_pad / TR::CO_T) * (p.ci_pad / TR::CI_T);
   const long per_slab = (long)TAPS * p.co_pad * p.ci_pad * 4 * (KSPLIT ? 4 : 1);
   long nsplit = std::max<long>(1, (1024 + tiles - 1) / tiles);
-  nsplit = std::min<long>(nsplit, std::max<long>(1, p.nstrips / 16));   // >= 16 strips per block: slabs cost a round trip
+  // >= 2048 pixels per block: every slab costs a round trip through HBM
+  nsplit = std::min<long>(nsplit, std::max<long>(1, (long)p.nstrips * HT * SW / 2048));
   nsplit = std::min<long>(nsplit, slab_bytes / per_slab);
   if (nsplit < 1) return dn_set_error(DN_ERR_ARG, "conv_wgrad: workspace of %ld bytes is smaller than one partial slab (%ld)",
                                       slab_bytes, per_slab);
   p.nsplit = (int)nsplit;
   *nslab_out = (int)nsplit * (KSPLIT ? 4 : 1);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW>), dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, HT>), dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

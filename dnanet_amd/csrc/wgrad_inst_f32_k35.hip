@@ -1,6 +1,9 @@
-// generated instantiation: conv_wgrad<float, 3, 5>
+// instantiations: conv_wgrad<float, 3, 5> with 5-, 3- and 1-row strips
 #include <algorithm>
 #include "conv_wgrad.h"
 int conv_wgrad_run_f32_k35(const WgradParams& p, long slab_bytes, int* nslab, hipStream_t s) {
-  return conv_wgrad_launch<float, 3, 5>(p, slab_bytes, nslab, s);
+  // same row-tile choice as the forward convolution (api.hip run_igemm): 6-dye profiles take 3-row tiles
+  if (p.H % 5 == 0) return conv_wgrad_launch<float, 3, 5, 5>(p, slab_bytes, nslab, s);
+  if (p.H % 3 == 0) return conv_wgrad_launch<float, 3, 5, 3>(p, slab_bytes, nslab, s);
+  return conv_wgrad_launch<float, 3, 5, 1>(p, slab_bytes, nslab, s);
 }

@@ -23,10 +23,10 @@ int main() {
   p.dy = dy; p.dy_pt = C / 16; p.dy_p0 = 0; p.dy_nplanes = C / 16; p.dy_gplanes = 1 << 30; p.dy_wmul = 1;
   p.a = a; p.a_pt = C / 16; p.a_p0 = 0; p.a_nplanes = C / 16; p.slab = slab; p.N = N; p.H = H; p.W = W; p.co_pad = C; p.ci_pad = C;
   int nslab; hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
-  for (int i = 0; i < 3; ++i) conv_wgrad_launch<__bf16, 3, 5>(p, 256L << 20, &nslab, s1);
+  for (int i = 0; i < 3; ++i) conv_wgrad_launch<__bf16, 3, 5, WG_HT>(p, 256L << 20, &nslab, s1);
   hipDeviceSynchronize();
   hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, s2, samples, NS, 10000LL);   // a sample every 100 us, 12 ms in all
-  for (int i = 0; i < 4; ++i) conv_wgrad_launch<__bf16, 3, 5>(p, 256L << 20, &nslab, s1);
+  for (int i = 0; i < 4; ++i) conv_wgrad_launch<__bf16, 3, 5, WG_HT>(p, 256L << 20, &nslab, s1);
   hipDeviceSynchronize();
   for (int i = 1; i < NS; ++i) {
     double dt = (samples[2 * i] - samples[2 * i - 2]) / 100.0;   // us

@@ -17,7 +17,7 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    for (int i = 0; i < 3; ++i) conv_wgrad_launch<__bf16, 3, 5>(p, 256L << 20, &nslab, 0);
+    for (int i = 0; i < 3; ++i) conv_wgrad_launch<__bf16, 3, 5, WG_HT>(p, 256L << 20, &nslab, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
     if (rep) printf("%s: %.1f us  %.1f TF/s (nslab %d)\n", VARIANT, ms * 1e3, 2.0 * N * H * W * C * C * 15 / ms / 1e9, nslab);
