@@ -42,6 +42,30 @@ int dn_set_error(int code, const char* fmt, ...);
   return dn_set_error(DN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 #define DN_LAUNCH_CHECK() DN_CHECK_HIP(hipGetLastError())
 
+// ---- LDS-DMA with buffer addressing (gfx950: buffer_load_dwordx4 ... lds)
+// Written as inline asm on purpose: hipcc neither drains nor counts it, so loads stay in flight across the ds_reads of
+// the tile being consumed and are waited for by hand (s_waitcnt vmcnt).  Buffer addressing keeps the per-piece VALU
+// work at (almost) nothing -- a 64-bit per-lane address plus a zero-page select per 16-B piece costs more issue slots
+// than the MFMAs it feeds: address = SRD base (uniform, moved by SALU) + 32-bit per-lane offset, and an offset
+// >= num_records (DN_OOB) makes the hardware write zeros, which is how padding, halos and image borders are filled.
+// The LDS destination is lane-linear: M0 + 16 * lane, so one wave-instruction fills 1 KiB.
+#define DN_OOB 0x80000000u
+typedef __attribute__((ext_vector_type(4))) unsigned dn_srd_t;
+__device__ __forceinline__ dn_srd_t dn_make_srd(const void* base) {
+  const unsigned long long b = (unsigned long long)base;
+  dn_srd_t r;
+  r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);   // stride 0: raw buffer
+  r.z = DN_OOB;                                                          // num_records (bytes)
+  r.w = 0x00020000u;                                                     // 32-bit untyped data format
+  return r;
+}
+__device__ __forceinline__ void dn_buffer_lds16(unsigned voff, dn_srd_t srd, unsigned lds_addr_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr_uniform) : "memory");
+}
+
 __device__ __forceinline__ float dn_to_float(float v) { return v; }
 __device__ __forceinline__ float dn_to_float(__bf16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T dn_from_float(float v);

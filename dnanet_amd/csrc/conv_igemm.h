@@ -18,9 +18,6 @@
 #pragma once
 #include "common.h"
 
-// source of zero-filled LDS pieces (image borders, padding)
-__device__ __attribute__((aligned(16))) const unsigned int dn_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
 struct ConvParams {
   const void* x; int x_planes_total, x_plane0, x_nplanes, x_gplanes, x_wmul;
   const void* w;            // packed [nchunk][TAPS][cout_pad][32 B]
@@ -50,23 +47,28 @@ template <> struct Mma32<float> {
   }
 };
 
-template <typename T, int KH, int KW, int HT, int COT>
+// EXACT = the image has exactly HT rows (the shipped 5-dye case): which (kernel row, output row) pairs fall outside
+// the image is then known at compile time and their MFMAs are left out (2 of 15 for 3x5); otherwise every pair runs
+// on the zero-filled halo rows.  Either way the MFMA loop has no branches, so fragment reads and MFMAs of a whole
+// chunk are scheduled as one block.
+template <typename T, int KH, int KW, int HT, int COT, bool EXACT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
   constexpr int ROWS = HT + KH - 1;
   constexpr int QW = 128 + KW - 1;
   constexpr int NCG = COT / 32;
   constexpr int EPR = RecTraits<T>::EPR;
-  constexpr int ACT_BYTES = ROWS * QW * 32;
+  constexpr int ACT_RAW = ROWS * QW * 32;
+  constexpr int ACT_BYTES = (ACT_RAW + 1023) / 1024 * 1024;          // weight image starts on a 1-KiB piece boundary
   constexpr int W_BYTES = TAPS * COT * 32;
-  constexpr int ACT_PIECES = ACT_BYTES / 16, W_PIECES = W_BYTES / 16;
-  constexpr int ST_ITERS = (ACT_PIECES + W_PIECES + 255) / 256;     // wave-instructions of 1 KiB per wave
-  constexpr int EPI_BYTES = 4 * (COT / EPR) * 1024;                 // epilogue scratch: 4 waves x planes x 1 KiB
+  constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 4095) / 4096;      // wave-instructions of 1 KiB per wave
+  constexpr int EPI_BYTES = 4 * (COT / EPR) * 1024;                  // epilogue scratch: 4 waves x planes x 1 KiB
   constexpr int SMEM_BYTES = ST_ITERS * 4096 > EPI_BYTES ? ST_ITERS * 4096 : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
   const int npt = p.N * p.nth * p.ntw;
@@ -78,27 +80,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const int w0 = tw * 128, h0 = th * HT;
   const int xrow = p.W * p.x_wmul;
 
-  // per-thread staging plan: LDS piece P = (it*4 + wave)*64 + lane of the linear image [act tile | weight tile | pad];
-  // st_off[it] = byte offset of its source inside the current plane / weight block (-1: zero fill)
-  int st_off[ST_ITERS];
-  unsigned st_isw = 0;
+  // per-thread staging plan: LDS piece P = (it*4 + wave)*64 + lane of the linear image [act tile | pad | weight tile];
+  // st_off[it] = byte offset of its source inside the current plane / weight block, DN_OOB = zero fill.  The tile
+  // position is fixed for the block, so the plan is made once and a chunk costs SALU work only (two SRD bases).
+  unsigned st_off[ST_ITERS];
   {
     const int xrow_b = p.W * p.x_wmul * 32;
 #pragma unroll
     for (int it = 0; it < ST_ITERS; ++it) {
-      const int P = (it * 4 + wave) * 64 + lane;
-      int off = -1;
-      if (P < ACT_PIECES) {
-        const int rq = P >> 1, pcl = P & 1;
+      const int byte = ((it * 4 + wave) * 64 + lane) * 16;
+      unsigned off = DN_OOB;
+      if (byte < ACT_RAW) {
+        const int rq = byte >> 5, pcl = (byte >> 4) & 1;
         const int r = rq / QW, q = rq - r * QW;
         const int h = h0 + r - PH, w = w0 + q - PW;
         if (h >= 0 && h < p.H && w >= 0 && w < p.W) off = h * xrow_b + w * p.x_wmul * 32 + 16 * (pcl ^ ((q >> 3) & 1));
-      } else if (P < ACT_PIECES + W_PIECES) {
-        const int Pw = P - ACT_PIECES;
-        const int tc = Pw >> 1, pcl = Pw & 1;
+      } else if (byte >= ACT_BYTES && byte < ACT_BYTES + W_BYTES) {
+        const int bw = byte - ACT_BYTES;
+        const int tc = bw >> 5, pcl = (bw >> 4) & 1;
         const int tap = tc / COT, co = tc - tap * COT;
         off = (tap * p.cout_pad + co) * 32 + 16 * (pcl ^ ((co >> 3) & 1));
-        st_isw |= 1u << it;
       }
       st_off[it] = off;
     }
@@ -121,19 +122,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     if (plane >= p.x_nplanes) continue;   // padding plane of a virtual group: weights are zero, data absent
     const long plane_base = ((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow;
     __syncthreads();   // previous chunk's fragment reads are done
-    // ---- stage activation + weight tiles straight into LDS (global_load_lds_dwordx4: no VGPR round trip,
-    // all pieces of the chunk in flight at once).  The LDS image is lane-linear per wave-instruction, so the
-    // XOR swizzle is applied to the per-lane SOURCE address (cdna_hip_programming.md, rule 21).
+    // ---- stage activation + weight tiles straight into LDS (LDS-DMA: no VGPR round trip, all pieces of the chunk
+    // in flight at once).  The LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the
+    // per-lane SOURCE offset (cdna_hip_programming.md, rule 21).
     {
-      const unsigned char* xplane = xb + plane_base * 32 + (long)grp * 32;
-      const unsigned char* wsrc = wb + ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32;
+      const dn_srd_t srd_x = dn_make_srd(xb + plane_base * 32 + (long)grp * 32);
+      const dn_srd_t srd_w = dn_make_srd(wb + ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32);
 #pragma unroll
       for (int it = 0; it < ST_ITERS; ++it) {
-        const int off = st_off[it];
-        const unsigned char* src = (const unsigned char*)dn_zero_page;
-        if (off >= 0) src = ((st_isw >> it) & 1) ? wsrc + off : xplane + off;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + (it * 4 + wave) * 1024), 16, 0, 0);
+        const bool is_w = (it * 4 + wave) * 1024 >= ACT_BYTES;          // wave-uniform
+        dn_buffer_lds16(st_off[it], is_w ? srd_w : srd_x, __builtin_amdgcn_readfirstlane(smem_lds + (it * 4 + wave) * 1024));
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -157,8 +155,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         }
 #pragma unroll
         for (int hh = 0; hh < HT; ++hh) {
-          const int hin = h0 + hh + dhi - PH;
-          if (h0 + hh < p.H && hin >= 0 && hin < p.H) {   // block-uniform
+          const int hin = hh + dhi - PH;                      // input row relative to the tile
+          if (!EXACT || (hin >= 0 && hin < HT)) {             // compile time
 #pragma unroll
             for (int cg = 0; cg < NCG; ++cg) Mma32<T>::run(af[cg], bf[hh + dhi], acc[hh][cg]);
           }
@@ -227,7 +225,11 @@ int conv_igemm_launch(ConvParams p, hipStream_t stream) {
   p.nth = (p.H + HT - 1) / HT;
   const long blocks = (long)p.N * p.ntw * p.nth * (p.cout_pad / COT);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  if ((long)p.H * p.W * p.x_wmul * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
+  if (KH > 1 && p.H == HT)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, (KH > 1)>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

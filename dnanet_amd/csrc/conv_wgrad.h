@@ -38,29 +38,6 @@ template <> struct WgTraits<float>  { static constexpr int CO_T = 32, CI_T = 32,
 // the L2 bandwidth bound to the MFMA bound (bytes staged per flop: x0.6 at HT = 5).
 template <typename T> constexpr int wg_strip_width(int ht) { return ht == 1 ? 64 : (sizeof(T) == 2 ? 32 : 16); }
 
-// LDS-DMA from inline asm: hipcc neither drains nor counts it, so the prefetch of the next strips stays in flight
-// across the ds_reads of the current one; it is waited for by hand (s_waitcnt vmcnt).  Buffer addressing keeps the
-// per-strip VALU work small -- a 64-bit per-lane address and a zero-page select per 16-B piece cost more issue slots
-// than the MFMAs they feed: address = SRD base (this image) + 32-bit (per-lane offset fixed for the whole kernel +
-// uniform strip offset), and an offset >= num_records (WG_OOB) makes the hardware write zeros, which is how padding,
-// halos and image borders are filled.
-#define WG_OOB 0x80000000u
-typedef __attribute__((ext_vector_type(4))) unsigned wg_srd_t;
-__device__ __forceinline__ wg_srd_t wg_make_srd(const void* base) {
-  const unsigned long long b = (unsigned long long)base;
-  wg_srd_t r;
-  r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
-  r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);   // stride 0: raw buffer
-  r.z = WG_OOB;                                                          // num_records (bytes)
-  r.w = 0x00020000u;                                                     // 32-bit untyped data format
-  return r;
-}
-__device__ __forceinline__ void wg_buffer_lds16(unsigned voff, wg_srd_t srd, unsigned lds_addr_uniform) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr_uniform) : "memory");
-}
-
 __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
   typedef __attribute__((ext_vector_type(4))) short s16x4;
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
@@ -173,15 +150,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 
   // staging of one strip = uniform set-up (SALU) + ST_ITERS independent pieces, so that the pieces of the next strip
   // can be sprinkled between the MFMAs of the current one instead of stalling the matrix pipe in one burst
-  struct StageCtx { wg_srd_t srd_dy, srd_a; unsigned so_dy, so_a, lds0; int h0, w0; };
+  struct StageCtx { dn_srd_t srd_dy, srd_a; unsigned so_dy, so_a, lds0; int h0, w0; };
   auto stage_begin = [&](int strip, int buf) {
     StageCtx c;
     const int tw = strip % p.ntw;
     const int n = strip / (p.ntw * p.nth);
     c.h0 = (strip / p.ntw) % p.nth * HT;
     c.w0 = tw * SW;
-    c.srd_dy = wg_make_srd(dyb + (long)(n * p.dy_pt + p.dy_p0) * p.H * dy_row * 32);
-    c.srd_a = wg_make_srd(ab + (long)(n * p.a_pt + p.a_p0) * p.H * p.W * 32);
+    c.srd_dy = dn_make_srd(dyb + (long)(n * p.dy_pt + p.dy_p0) * p.H * dy_row * 32);
+    c.srd_a = dn_make_srd(ab + (long)(n * p.a_pt + p.a_p0) * p.H * p.W * 32);
     c.so_dy = (unsigned)(((long)c.h0 * dy_row + (long)c.w0 * p.dy_wmul) * 32);
     c.so_a = (unsigned)(((long)c.h0 * p.W + c.w0) * 32);
     c.lds0 = smem_lds + buf * BUF_BYTES + wave * 1024;
@@ -190,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   auto stage_piece = [&](const StageCtx& c, int it) {
     const bool is_a = (it * 4 + wave) * 1024 >= DY_BYTES;              // wave-uniform
     const bool ok = ((unsigned)(c.h0 + st_row[it]) < (unsigned)p.H) & ((unsigned)(c.w0 + st_col[it]) < (unsigned)p.W);
-    const unsigned off = ok ? st_off[it] + (is_a ? c.so_a : c.so_dy) : WG_OOB;
-    wg_buffer_lds16(off, is_a ? c.srd_a : c.srd_dy, __builtin_amdgcn_readfirstlane(c.lds0 + it * 4096));
+    const unsigned off = ok ? st_off[it] + (is_a ? c.so_a : c.so_dy) : DN_OOB;
+    dn_buffer_lds16(off, is_a ? c.srd_a : c.srd_dy, __builtin_amdgcn_readfirstlane(c.lds0 + it * 4096));
   };
   // a strip past the end is still "staged", with every offset out of range (zeros into a buffer nobody reads): the
   // loops stay branch-free and the vmcnt arithmetic is the same for every strip
