@@ -63,17 +63,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   constexpr int W_BYTES = TAPS * COT * 32;
   constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 4095) / 4096;      // wave-instructions of 1 KiB per wave
   constexpr int EPI_BYTES = 4 * (COT / EPR) * 1024;                  // epilogue scratch: 4 waves x planes x 1 KiB
-  constexpr int SMEM_BYTES = ST_ITERS * 4096 > EPI_BYTES ? ST_ITERS * 4096 : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-  const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  constexpr int BUF_BYTES = ST_ITERS * 4096;
+  // K chunks are software pipelined through NBUF LDS images when two workgroups of them fit a CU (1x1 / 1x3 kernels:
+  // a chunk is only HT*NCG MFMAs per wave, far less than a load latency); the 3x5 images are too big for that and
+  // rely on the CU's other workgroup to cover their load phase.
+  constexpr int NBUF = 2 * 3 * BUF_BYTES <= 160 * 1024 ? 3 : (2 * 2 * BUF_BYTES <= 160 * 1024 ? 2 : 1);
+  static_assert((NBUF - 1) * ST_ITERS < 64, "vmcnt is a 6-bit counter");
+  constexpr int SMEM_BYTES = NBUF * BUF_BYTES > EPI_BYTES ? NBUF * BUF_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_all[SMEM_BYTES];
+  const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
+  // block -> tile map, XCD aware (blocks b and b+8 share an XCD and its L2): inside an XCD the output-channel tile is
+  // the fast index, so the blocks that need the same activation tile run at the same time on the same L2 and the
+  // tile comes from HBM once instead of once per channel tile; pixel tiles are dealt round-robin to the 8 XCDs.
   const int npt = p.N * p.nth * p.ntw;
-  const int cot = blockIdx.x / npt;
-  int pt = blockIdx.x - cot * npt;
+  const int ncot = p.cout_pad / COT;
+  const int j = blockIdx.x >> 3;
+  const int cot = j % ncot;
+  int pt = (j / ncot) * 8 + (blockIdx.x & 7);
+  if (pt >= npt) return;                 // whole block: the grid is padded to a multiple of 8 pixel tiles
   const int tw = pt % p.ntw; pt /= p.ntw;
   const int th = pt % p.nth;
   const int n = pt / p.nth;
@@ -116,26 +128,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const unsigned char* xb = (const unsigned char*)p.x;
   const unsigned char* wb = (const unsigned char*)p.w;
 
-  for (int ck = 0; ck < p.nchunk; ++ck) {
+  // stage chunk ck into LDS image buf (LDS-DMA: no VGPR round trip, all pieces of the chunk in flight at once).  The
+  // LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the per-lane SOURCE offset
+  // (cdna_hip_programming.md, rule 21).  A chunk that does not exist (past the end, or the padding plane of a virtual
+  // group, whose weights are zero) is staged from an empty buffer = all zeros, which keeps loops and vmcnt uniform.
+  auto stage = [&](int ck, int buf) {
     const int grp = ck / p.x_gplanes;
     const int plane = ck - grp * p.x_gplanes;
-    if (plane >= p.x_nplanes) continue;   // padding plane of a virtual group: weights are zero, data absent
+    const bool exists = ck < p.nchunk && plane < p.x_nplanes;
     const long plane_base = ((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow;
-    __syncthreads();   // previous chunk's fragment reads are done
-    // ---- stage activation + weight tiles straight into LDS (LDS-DMA: no VGPR round trip, all pieces of the chunk
-    // in flight at once).  The LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the
-    // per-lane SOURCE offset (cdna_hip_programming.md, rule 21).
-    {
-      const dn_srd_t srd_x = dn_make_srd(xb + plane_base * 32 + (long)grp * 32);
-      const dn_srd_t srd_w = dn_make_srd(wb + ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32);
+    dn_srd_t srd_x = dn_make_srd(xb + (exists ? plane_base * 32 + (long)grp * 32 : 0));
+    dn_srd_t srd_w = dn_make_srd(wb + (exists ? ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32 : 0));
+    if (!exists) { srd_x.z = 0; srd_w.z = 0; }
 #pragma unroll
-      for (int it = 0; it < ST_ITERS; ++it) {
-        const bool is_w = (it * 4 + wave) * 1024 >= ACT_BYTES;          // wave-uniform
-        dn_buffer_lds16(st_off[it], is_w ? srd_w : srd_x, __builtin_amdgcn_readfirstlane(smem_lds + (it * 4 + wave) * 1024));
-      }
+    for (int it = 0; it < ST_ITERS; ++it) {
+      const bool is_w = (it * 4 + wave) * 1024 >= ACT_BYTES;          // wave-uniform
+      dn_buffer_lds16(st_off[it], is_w ? srd_w : srd_x,
+                      __builtin_amdgcn_readfirstlane(smem_lds + buf * BUF_BYTES + (it * 4 + wave) * 1024));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+
+  int buf = 0;
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) stage(i, i);
+  for (int ck = 0; ck < p.nchunk; ++ck, buf = buf + 1 == NBUF ? 0 : buf + 1) {
+    if constexpr (NBUF == 1) {
+      __syncthreads();   // previous chunk's fragment reads are done
+      stage(ck, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
+      // LDS-DMA completes in issue order: all but the newest NBUF-2 chunks in flight have landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ST_ITERS) : "memory");
+      __syncthreads();   // everyone's pieces of chunk ck landed; everyone left the image of chunk ck-1
+      stage(ck + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
+    }
+    const unsigned char* smem = smem_all + buf * BUF_BYTES;
     // ---- MFMA over all taps
 #pragma unroll
     for (int dwi = 0; dwi < KW; ++dwi) {
@@ -169,8 +197,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   // every global store instruction writes 1 KiB of consecutive 16-byte pieces (32 pixels of one plane row)
   // instead of 8-byte fragments at a 32-byte stride.
   constexpr int NPL = COT / EPR;                    // output planes of this tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land on the scratch (or outlive the wave)
   __syncthreads();                                  // all waves are done reading the staged tiles
-  unsigned char* scratch = smem + wave * (NPL * 1024);
+  unsigned char* scratch = smem_all + wave * (NPL * 1024);
   unsigned char* yb = (unsigned char*)p.y;
   const int yrow = p.W * p.y_wmul;
   const int wbase = w0 + 32 * wave;
@@ -223,7 +252,7 @@ template <typename T, int KH, int KW, int HT, int COT>
 int conv_igemm_launch(ConvParams p, hipStream_t stream) {
   p.ntw = (p.W + 127) / 128;
   p.nth = (p.H + HT - 1) / HT;
-  const long blocks = (long)p.N * p.ntw * p.nth * (p.cout_pad / COT);
+  const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / COT);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * p.x_wmul * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
   if (KH > 1 && p.H == HT)
