@@ -16,6 +16,7 @@
 // 16-byte pieces inside a record are XOR-swizzled by bit 3 of the record index, which makes every
 // ds_read_b128 of a fragment conflict-free for any tap shift (MI355X_MICROARCH.md, LDS table).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 struct ConvParams {
@@ -47,11 +48,12 @@ template <> struct Mma32<float> {
   }
 };
 
-// EXACT = the image has exactly HT rows (the shipped 5-dye case): which (kernel row, output row) pairs fall outside
-// the image is then known at compile time and their MFMAs are left out (2 of 15 for 3x5); otherwise every pair runs
-// on the zero-filled halo rows.  Either way the MFMA loop has no branches, so fragment reads and MFMAs of a whole
-// chunk are scheduled as one block.
-template <typename T, int KH, int KW, int HT, int COT, bool EXACT>
+// A tile whose halo row lies above / below the image (every tile of the shipped 5-dye case, half the tiles of the
+// 6-dye one) leaves out the MFMAs of the (kernel row, output row) pairs that only see that zero row: 2 of 15 for 3x5
+// with both.  The choice is per block, so the chunk loop exists in four compile-time variants and each block runs
+// one; inside a variant the MFMA loop has no branches, so the fragment reads and MFMAs of a whole chunk are
+// scheduled as one basic block.
+template <typename T, int KH, int KW, int HT, int COT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
   constexpr int ROWS = HT + KH - 1;
@@ -148,9 +150,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
   };
 
-  int buf = 0;
 #pragma unroll
   for (int i = 0; i < NBUF - 1; ++i) stage(i, i);
+  auto mainloop = [&](auto skip_top_c, auto skip_bot_c) {
+  constexpr bool SKIP_TOP = decltype(skip_top_c)::value, SKIP_BOT = decltype(skip_bot_c)::value;
+  int buf = 0;
   for (int ck = 0; ck < p.nchunk; ++ck, buf = buf + 1 == NBUF ? 0 : buf + 1) {
     if constexpr (NBUF == 1) {
       __syncthreads();   // previous chunk's fragment reads are done
@@ -184,13 +188,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
         for (int hh = 0; hh < HT; ++hh) {
           const int hin = hh + dhi - PH;                      // input row relative to the tile
-          if (!EXACT || (hin >= 0 && hin < HT)) {             // compile time
+          if (!(SKIP_TOP && hin < 0) && !(SKIP_BOT && hin >= HT)) {   // compile time
 #pragma unroll
             for (int cg = 0; cg < NCG; ++cg) Mma32<T>::run(af[cg], bf[hh + dhi], acc[hh][cg]);
           }
         }
       }
     }
+  }
+
+  };
+  {
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    const bool top = KH > 1 && h0 == 0, bot = KH > 1 && h0 + HT >= p.H;   // block-uniform
+    if constexpr (KH == 1) mainloop(no{}, no{});
+    else if (top && bot) mainloop(yes{}, yes{});
+    else if (top) mainloop(yes{}, no{});
+    else if (bot) mainloop(no{}, yes{});
+    else mainloop(no{}, no{});
   }
 
   // ---- epilogue: bias (+ folded BN) + ReLU in registers, then through a wave-private LDS scratch so that
@@ -255,10 +271,7 @@ int conv_igemm_launch(ConvParams p, hipStream_t stream) {
   const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / COT);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * p.x_wmul * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
-  if (KH > 1 && p.H == HT)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, (KH > 1)>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }
