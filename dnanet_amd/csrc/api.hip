@@ -21,6 +21,11 @@ static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t
   if (kh == 3 && kw == 5 && p.H % 3 == 0 && p.H % 5 != 0) ht = 3;   // e.g. 6 dye rows = two 3-row tiles
   static const char* force_cot = getenv("DN_TUNE_COT");      // tuning aid: DN_TUNE_COT=32 forces the narrow tile
   if (force_cot && atoi(force_cot) == 32) cot = 32;
+  static const char* no8 = getenv("DN_TUNE_NO_CONV8");        // tuning aid: keep the 4-wave kernel everywhere
+  // measured (N=256, W=4096 net): 8-wave wins for 5-row tiles and for fp32; bf16 3-row tiles have too few MFMAs per
+  // barrier step and stay on the 4-wave kernel
+  if (!no8 && cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && ht == 5)))
+    return dtype == DN_BF16 ? conv_igemm8_run_bf16(p, ht, s) : conv_igemm8_run_f32(p, ht, s);
   if (dtype == DN_BF16) {
     if (kh == 3 && kw == 5) return conv_igemm_run_bf16_k35(p, ht, cot, s);
     if (kh == 1 && kw == 3) return conv_igemm_run_bf16_k13(p, ht, cot, s);

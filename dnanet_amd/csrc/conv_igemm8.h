@@ -1,0 +1,271 @@
+// 3x5 implicit-GEMM convolution, 8-wave software-pipelined variant for the mid / deep U-Net levels (gfx950).
+//
+// Same operator, operands, LDS swizzle and epilogue as conv_igemm.h (reference unet_architecture.py:14-20); what
+// changes is the schedule.  conv_igemm.h stages one K chunk, waits, computes, and relies on the CU's second
+// workgroup to cover the load phase; per chunk each of the two workgroups pulls its own weight tile, and the L2->LDS
+// path (about 20 B/clk per CU) ends up as busy as the matrix pipe.  Here ONE workgroup of 8 waves owns the CU:
+//   * tile = HT dye rows x 256 scan columns x 64 output channels: the 30-KB weight tile of a chunk is shared by twice
+//     the pixels (bytes staged per MFMA x0.73);
+//   * the activation tile is double buffered: chunk k+1 streams in (LDS-DMA) during the first two of the five
+//     kernel-column steps of chunk k;
+//   * the weight tile is kept once, as five kernel-column slices [dwi][dhi][co]: the slice a step has just finished
+//     with is refilled with the slice the same step needs four steps later (next chunk) -- a ring with a fixed lead;
+//   * one barrier per kernel-column step; every wave issues the same number of LDS-DMA pieces per step (dummy pieces
+//     go to a scrap KiB), so "my loads older than the newest N have landed" is a compile-time vmcnt per step.
+// LDS: 2 x act (<= 57 KiB) + 30 KiB weights + 1 KiB scrap <= 146 KiB of the CU's 160.
+#pragma once
+#include <type_traits>
+#include "conv_igemm.h"
+
+template <typename T, int HT>
+__global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p) {
+  constexpr int KH = 3, KW = 5, PH = 1, PW = 2, COT = 64, NCG = 2, TW = 256;
+  constexpr int ROWS = HT + KH - 1;
+  constexpr int QW = TW + KW - 1;
+  constexpr int EPR = RecTraits<T>::EPR;
+  constexpr int ACT_RAW = ROWS * QW * 32;
+  constexpr int ACT_PIECES = (ACT_RAW + 1023) / 1024;
+  constexpr int ACT_STEPS = 2;                                        // kernel-column steps that carry act pieces
+  constexpr int APW = (ACT_PIECES + 8 * ACT_STEPS - 1) / (8 * ACT_STEPS);   // act pieces per wave per such step
+  constexpr int ACT_BUF = ACT_PIECES * 1024;
+  constexpr int W_SLICE = KH * COT * 32;                              // one kernel column: 6 pieces, waves 0..5
+  constexpr int W_OFF = 2 * ACT_BUF, SCRAP_OFF = W_OFF + KW * W_SLICE;
+  constexpr int SMEM_BYTES = SCRAP_OFF + 1024;
+  static_assert(W_SLICE == 6 * 1024 && SMEM_BYTES <= 160 * 1024, "LDS plan");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // block -> tile map: as conv_igemm.h (channel tiles fast inside an XCD)
+  const int npt = p.N * p.nth * p.ntw;
+  const int ncot = p.cout_pad / COT;
+  const int j = blockIdx.x >> 3;
+  const int cot = j % ncot;
+  int pt = (j / ncot) * 8 + (blockIdx.x & 7);
+  if (pt >= npt) return;
+  const int tw = pt % p.ntw; pt /= p.ntw;
+  const int th = pt % p.nth;
+  const int n = pt / p.nth;
+  const int w0 = tw * TW, h0 = th * HT;
+  const int xrow = p.W * p.x_wmul;
+
+  // staging plan, fixed for the block.  Activation piece P = i*8 + wave (i < ACT_STEPS*APW) of the linear tile image;
+  // weight piece = wave (< 6) of a kernel-column slice, relative to that slice's first tap.
+  unsigned a_off[ACT_STEPS * APW];
+  {
+    const int xrow_b = xrow * 32;
+#pragma unroll
+    for (int i = 0; i < ACT_STEPS * APW; ++i) {
+      const int byte = ((i * 8 + wave) * 64 + lane) * 16;
+      unsigned off = DN_OOB;
+      if (byte < ACT_RAW) {
+        const int rq = byte >> 5, pcl = (byte >> 4) & 1;
+        const int r = rq / QW, q = rq - r * QW;
+        const int h = h0 + r - PH, w = w0 + q - PW;
+        if (h >= 0 && h < p.H && w >= 0 && w < p.W) off = h * xrow_b + w * p.x_wmul * 32 + 16 * (pcl ^ ((q >> 3) & 1));
+      }
+      a_off[i] = off;
+    }
+  }
+  unsigned w_off = DN_OOB;
+  if (wave < 6) {
+    const int byte = (wave * 64 + lane) * 16;
+    const int tc = byte >> 5, pcl = (byte >> 4) & 1;
+    const int dhi = tc / COT, co = tc - dhi * COT;
+    w_off = (unsigned)((dhi * KW * p.cout_pad + co) * 32 + 16 * (pcl ^ ((co >> 3) & 1)));
+  }
+
+  const unsigned char* xb = (const unsigned char*)p.x;
+  const unsigned char* wb = (const unsigned char*)p.w;
+  // a chunk that does not exist (past the end / padding plane of a virtual group) reads from an empty buffer = zeros
+  auto chunk_exists = [&](int ck) { return ck < p.nchunk && (ck % p.x_gplanes) < p.x_nplanes; };
+  auto srd_act = [&](int ck) {
+    const int grp = ck / p.x_gplanes, plane = ck - grp * p.x_gplanes;
+    const bool ex = chunk_exists(ck);
+    dn_srd_t s = dn_make_srd(xb + (ex ? (((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow + grp) * 32 : 0));
+    if (!ex) s.z = 0;
+    return s;
+  };
+  auto srd_wslice = [&](int ck, int dwi) {
+    const bool ex = chunk_exists(ck);
+    dn_srd_t s = dn_make_srd(wb + (ex ? (((long)ck * KH * KW + dwi) * p.cout_pad + (long)cot * COT) * 32 : 0));
+    if (!ex) s.z = 0;
+    return s;
+  };
+  auto issue_act = [&](const dn_srd_t& srd, int abuf, int step) {     // APW pieces of one activation image
+#pragma unroll
+    for (int k = 0; k < APW; ++k) {
+      const int i = step * APW + k;
+      const bool real = (i * 8 + wave) < ACT_PIECES;                  // wave-uniform; the rest lands on the scrap KiB
+      dn_buffer_lds16(a_off[i], srd, __builtin_amdgcn_readfirstlane(
+                          smem_lds + (real ? abuf * ACT_BUF + (i * 8 + wave) * 1024 : SCRAP_OFF)));
+    }
+  };
+  auto issue_w = [&](const dn_srd_t& srd, int dwi) {                  // one piece of one weight slice
+    dn_buffer_lds16(w_off, srd, __builtin_amdgcn_readfirstlane(smem_lds + (wave < 6 ? W_OFF + dwi * W_SLICE + wave * 1024 : SCRAP_OFF)));
+  };
+
+  f32x16_t acc[HT][NCG];
+#pragma unroll
+  for (int a = 0; a < HT; ++a)
+#pragma unroll
+    for (int b = 0; b < NCG; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // ---- prologue: chunk 0 entirely
+  {
+    const dn_srd_t sa = srd_act(0);
+#pragma unroll
+    for (int s = 0; s < ACT_STEPS; ++s) issue_act(sa, 0, s);
+#pragma unroll
+    for (int dwi = 0; dwi < KW; ++dwi) issue_w(srd_wslice(0, dwi), dwi);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  auto mainloop = [&](auto skip_top_c, auto skip_bot_c) {
+    constexpr bool SKIP_TOP = decltype(skip_top_c)::value, SKIP_BOT = decltype(skip_bot_c)::value;
+    // fragments of the NEXT step are read at the end of the current one (activation rows: all; weights: kernel row 0),
+    // so that after a barrier the matrix pipe starts at once instead of waiting for all 8 waves' LDS reads
+    uint4 bf[ROWS], af0[NCG];
+    auto load_bf = [&](const unsigned char* act, int dwi) {
+      const int q = 32 * wave + l31 + dwi;
+      const int boff = q * 32 + 16 * (half ^ ((q >> 3) & 1));
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) bf[r] = *(const uint4*)(act + r * QW * 32 + boff);
+    };
+    auto load_af = [&](uint4 (&af)[NCG], int dwi, int dhi) {
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        const int col = cg * 32 + l31;
+        af[cg] = *(const uint4*)(smem + W_OFF + dwi * W_SLICE + (dhi * COT + col) * 32 + 16 * (half ^ ((col >> 3) & 1)));
+      }
+    };
+    __syncthreads();   // prologue pieces of every wave have landed
+    load_bf(smem, 0);
+    load_af(af0, 0, 0);
+    for (int ck = 0; ck < p.nchunk; ++ck) {
+      const unsigned char* act = smem + (ck & 1) * ACT_BUF;
+      const unsigned char* act_next = smem + ((ck + 1) & 1) * ACT_BUF;
+      const dn_srd_t sa_next = srd_act(ck + 1);
+      auto step = [&](auto dwi_c) {
+        constexpr int dwi = decltype(dwi_c)::value;
+        // Per wave and step the issue order is [act pieces (steps 0, 1 only), weight piece].  At the top of a step the
+        // weight slice of the NEXT step (issued three steps ago) must have landed -- and at step 4 the next chunk's
+        // activations (issued in steps 0-1, older); everything issued after that may still be in flight:
+        constexpr int NEWER = dwi == 0 ? 2 : dwi == 1 ? 2 + APW : dwi == 2 ? 2 + 2 * APW : dwi == 3 ? 2 + APW : 2;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+        __syncthreads();   // everyone's pieces landed; everyone is done with the previous step's slice / act image
+        if (dwi < ACT_STEPS) issue_act(sa_next, (ck + 1) & 1, dwi);
+        // refill the slice the previous step finished with: step 0 -> slice 4 of THIS chunk, step d -> slice d-1 of the next
+        if (dwi == 0) issue_w(srd_wslice(ck, KW - 1), KW - 1);
+        else issue_w(srd_wslice(ck + 1, dwi - 1), dwi - 1);
+
+        // weight fragments rotate through two register sets: row 1 is read before row 0's MFMAs, row 2 after them
+        uint4 af1[NCG];
+        load_af(af1, dwi, 1);
+#pragma unroll
+        for (int dhi = 0; dhi < KH; ++dhi) {
+#pragma unroll
+          for (int hh = 0; hh < HT; ++hh) {
+            const int hin = hh + dhi - PH;
+            if (!(SKIP_TOP && hin < 0) && !(SKIP_BOT && hin >= HT)) {   // compile time
+#pragma unroll
+              for (int cg = 0; cg < NCG; ++cg) Mma32<T>::run(dhi == 1 ? af1[cg] : af0[cg], bf[hh + dhi], acc[hh][cg]);
+            }
+          }
+          if (dhi == 0) load_af(af0, dwi, 2);
+        }
+        // next step's fragments
+        if (dwi + 1 < KW) load_bf(act, dwi + 1); else load_bf(act_next, 0);
+        load_af(af0, (dwi + 1) % KW, 0);
+      };
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 4>{});
+    }
+  };
+  {
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    const bool top = h0 == 0, bot = h0 + HT >= p.H;   // block-uniform
+    if (top && bot) mainloop(yes{}, yes{});
+    else if (top) mainloop(yes{}, no{});
+    else if (bot) mainloop(no{}, yes{});
+    else mainloop(no{}, no{});
+  }
+
+  // ---- epilogue: as conv_igemm.h (bias + ReLU in registers, wave-private LDS scratch, 1-KiB stores)
+  constexpr int NPL = COT / EPR;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned char* scratch = smem + wave * (NPL * 1024);
+  unsigned char* yb = (unsigned char*)p.y;
+  const int yrow = p.W * p.y_wmul;
+  const int wbase = w0 + 32 * wave;
+#pragma unroll
+  for (int hh = 0; hh < HT; ++hh) {
+    const int h = h0 + hh;
+    if (h < p.H) {                                  // block-uniform
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = cg * 32 + 8 * g + 4 * half;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[hh][cg][4 * g + i];
+            if (p.bias) v[i] += p.bias[cot * COT + cl + i];
+            if (p.relu) v[i] = fmaxf(v[i], 0.f);
+          }
+          unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
+          if constexpr (sizeof(T) == 4) {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
+            uint2 u;
+            u.x = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
+            u.y = (uint32_t)__builtin_bit_cast(unsigned short, b2) | ((uint32_t)__builtin_bit_cast(unsigned short, b3) << 16);
+            *(uint2*)dst = u;
+          }
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const int vplane = cot * NPL + pl;
+        const int ygrp = vplane / p.y_gplanes;
+        const int yplane = vplane - ygrp * p.y_gplanes;
+        const int px = lane >> 1, pc = lane & 1;
+        const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
+        if (yplane < p.y_nplanes && wbase + px < p.W) {
+          const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
+                           (long)(wbase + px) * p.y_wmul + ygrp;
+          *(uint4*)(yb + rec * 32 + 16 * pc) = val;
+        }
+      }
+    }
+  }
+}
+
+// the 8-wave kernel pays off once a block has enough K chunks to pipeline and the row holds whole 256-column tiles
+inline bool conv_igemm8_applies(const ConvParams& p, int kh, int kw) {
+  return kh == 3 && kw == 5 && p.cout_pad % 64 == 0 && p.W % 256 == 0 && p.nchunk >= 4 && p.x_wmul == 1 && p.y_wmul == 1;
+}
+
+template <typename T, int HT>
+int conv_igemm8_launch(ConvParams p, hipStream_t stream) {
+  p.ntw = p.W / 256;
+  p.nth = (p.H + HT - 1) / HT;
+  const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / 64);
+  if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
+  if ((long)p.H * p.W * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
+  hipLaunchKernelGGL((conv_igemm8_kernel<T, HT>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
