@@ -142,12 +142,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     dn_srd_t srd_x = dn_make_srd(xb + (exists ? plane_base * 32 + (long)grp * 32 : 0));
     dn_srd_t srd_w = dn_make_srd(wb + (exists ? ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32 : 0));
     if (!exists) { srd_x.z = 0; srd_w.z = 0; }
+#ifndef CV_ABLATE_NO_STAGE   // (ablation hooks: scratch/conv_micro.hip)
 #pragma unroll
     for (int it = 0; it < ST_ITERS; ++it) {
       const bool is_w = (it * 4 + wave) * 1024 >= ACT_BYTES;          // wave-uniform
       dn_buffer_lds16(st_off[it], is_w ? srd_w : srd_x,
                       __builtin_amdgcn_readfirstlane(smem_lds + buf * BUF_BYTES + (it * 4 + wave) * 1024));
     }
+#endif
   };
 
 #pragma unroll
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
     const unsigned char* smem = smem_all + buf * BUF_BYTES;
     // ---- MFMA over all taps
+#ifndef CV_ABLATE_NO_COMPUTE
 #pragma unroll
     for (int dwi = 0; dwi < KW; ++dwi) {
       uint4 bf[ROWS];
@@ -195,6 +198,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         }
       }
     }
+#else
+    (void)smem;
+#endif
   }
 
   };
@@ -254,6 +260,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         const int yplane = vplane - ygrp * p.y_gplanes;
         const int px = lane >> 1, pc = lane & 1;
         const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
+#ifdef CV_ABLATE_NO_STORE
+        if (val.x == 0x12345678u)
+#endif
         if (yplane < p.y_nplanes && wbase + px < p.W) {
           const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
                            (long)(wbase + px) * p.y_wmul + ygrp;
