@@ -72,6 +72,20 @@ def cpu_baseline(rows: int, seconds_budget: float = 20.0):
 TRAIN_FLOP_H5 = 175_574_876_160        # fwd + dgrad + wgrad per profile, H=5
 
 
+def hbm_traffic_per_launch(tag):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the figure
+    comes from the committed rocprofv3 passes of this same command (profiles/README.md; 2 x FETCH_SIZE + WRITE_SIZE,
+    the gfx950 correction of MI355X_MICROARCH.md) and is reported only when it was measured for the kernel that
+    dominates this run; otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return round(rec["traffic_bytes_per_launch"]) if rec.get("kernel") == tag else None
+
+
 def train_leg(args, dev, rank, world, distributed, x, t, barrier):
     """fwd (batch-stat BN) + Dice + bwd + Adam on the same synthetic batch; data parallel over RCCL when N > 1
     (global batch = 256 x N, Dice sums and the gradient arena all-reduced; BASELINE.json configs[2]/[3])."""
@@ -179,7 +193,7 @@ def main():
         peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
         achieved = fl / sec / 1e12
         roofline = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None, "launches": cnt,
+                    "frac": round(achieved / peak, 4), "traffic": hbm_traffic_per_launch(tag), "launches": cnt,
                     "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "share_of_step_time": round(sec / elapsed, 3),
                     "whole_net_frac": round(value / world * flop_per_profile / 1e12 / peak, 4)}
