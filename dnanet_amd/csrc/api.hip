@@ -15,17 +15,29 @@ int dn_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t s) {
-  int cot = (p.cout_pad % 64 == 0) ? 64 : 32;
-  int ht = 5;
-  if (kh == 3 && kw == 5 && p.H % 3 == 0 && p.H % 5 != 0) ht = 3;   // e.g. 6 dye rows = two 3-row tiles
+// Which instantiation a convolution goes to.  One function, used by the dispatcher and by dn_conv2d_variant (the
+// name bench.py groups launches by), so the two cannot drift apart.
+struct ConvVariant { bool wave8; int ht, cot; };
+static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype) {
+  ConvVariant v{false, 5, (p.cout_pad % 64 == 0) ? 64 : 32};
+  if (kh == 3 && kw == 5 && p.H % 3 == 0 && p.H % 5 != 0) v.ht = 3;   // e.g. 6 dye rows = two 3-row tiles
   static const char* force_cot = getenv("DN_TUNE_COT");      // tuning aid: DN_TUNE_COT=32 forces the narrow tile
-  if (force_cot && atoi(force_cot) == 32) cot = 32;
+  if (force_cot && atoi(force_cot) == 32) v.cot = 32;
+  // narrow (32-channel) tiles have room for 6 accumulator rows: one 6-row tile instead of two 3-row ones halves the
+  // per-block fixed cost that dominates the 2-4 chunk layers
+  if (kh == 3 && kw == 5 && v.cot == 32 && v.ht == 3 && p.H % 6 == 0) v.ht = 6;
   static const char* no8 = getenv("DN_TUNE_NO_CONV8");        // tuning aid: keep the 4-wave kernel everywhere
-  // measured (N=256, W=4096 net): 8-wave wins for 5-row tiles and for fp32; bf16 3-row tiles have too few MFMAs per
-  // barrier step and stay on the 4-wave kernel
-  if (!no8 && cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && ht == 5)))
-    return dtype == DN_BF16 ? conv_igemm8_run_bf16(p, ht, s) : conv_igemm8_run_f32(p, ht, s);
+  // measured (N=256, W=4096 net): the 8-wave kernels win for 5-row tiles and for fp32; bf16 3-row tiles (6 dyes) are
+  // faster on the 4-wave kernel at every level
+  v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && v.ht == 5));
+  return v;
+}
+
+static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t s) {
+  if (dtype != DN_BF16 && dtype != DN_F32) return dn_set_error(DN_ERR_ARG, "bad dtype %d", dtype);
+  const ConvVariant v = choose_variant(p, kh, kw, dtype);
+  const int ht = v.ht, cot = v.cot;
+  if (v.wave8) return dtype == DN_BF16 ? conv_igemm8_run_bf16(p, ht, s) : conv_igemm8_run_f32(p, ht, s);
   if (dtype == DN_BF16) {
     if (kh == 3 && kw == 5) return conv_igemm_run_bf16_k35(p, ht, cot, s);
     if (kh == 1 && kw == 3) return conv_igemm_run_bf16_k13(p, ht, cot, s);
@@ -50,6 +62,17 @@ extern "C" {
 
 const char* dn_last_error(void) { return g_err; }
 int dn_abi_version(void) { return 1; }
+
+int dn_conv2d_variant(int cin, int cout, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len) {
+  DN_CHECK_ARG(buf && buf_len > 0, "dn_conv2d_variant: no buffer");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d_variant: bad dtype %d", dtype);
+  ConvParams p{};
+  p.H = H; p.W = W; p.nchunk = dn_planes(cin, dtype); p.cout_pad = dn_channel_pad(cout); p.x_wmul = 1; p.y_wmul = 1;
+  const ConvVariant v = choose_variant(p, kh, kw, dtype);
+  snprintf(buf, buf_len, "%s<%s,%dx%d,ht%d,cot%d>", v.wave8 ? (v.ht == 3 ? "conv_igemm8c" : "conv_igemm8") : "conv_igemm",
+           dtype == DN_BF16 ? "bf16" : "f32", kh, kw, v.ht, v.cot);
+  return DN_OK;
+}
 
 int dn_conv2d(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
               int relu, int dtype, void* stream) {

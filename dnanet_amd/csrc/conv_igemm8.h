@@ -17,6 +17,59 @@
 #include <type_traits>
 #include "conv_igemm.h"
 
+// epilogue shared by the 8-wave kernels: as conv_igemm.h (bias + ReLU in registers, wave-private LDS scratch, 1-KiB stores)
+template <typename T, int HT, int COT>
+__device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_t (&acc)[HT][COT / 32], unsigned char* scratch,
+                                                    int n, int h0, int wbase, int cot, int lane) {
+  constexpr int NCG = COT / 32, EPR = RecTraits<T>::EPR, NPL = COT / EPR;
+  const int l31 = lane & 31, half = lane >> 5;
+  unsigned char* yb = (unsigned char*)p.y;
+  const int yrow = p.W * p.y_wmul;
+#pragma unroll
+  for (int hh = 0; hh < HT; ++hh) {
+    const int h = h0 + hh;
+    if (h < p.H) {                                  // block-uniform
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = cg * 32 + 8 * g + 4 * half;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[hh][cg][4 * g + i];
+            if (p.bias) v[i] += p.bias[cot * COT + cl + i];
+            if (p.relu) v[i] = fmaxf(v[i], 0.f);
+          }
+          unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
+          if constexpr (sizeof(T) == 4) {
+            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
+            uint2 u;
+            u.x = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
+            u.y = (uint32_t)__builtin_bit_cast(unsigned short, b2) | ((uint32_t)__builtin_bit_cast(unsigned short, b3) << 16);
+            *(uint2*)dst = u;
+          }
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const int vplane = cot * NPL + pl;
+        const int ygrp = vplane / p.y_gplanes;
+        const int yplane = vplane - ygrp * p.y_gplanes;
+        const int px = lane >> 1, pc = lane & 1;
+        const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
+        if (yplane < p.y_nplanes && wbase + px < p.W) {
+          const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
+                           (long)(wbase + px) * p.y_wmul + ygrp;
+          *(uint4*)(yb + rec * 32 + 16 * pc) = val;
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int HT>
 __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p) {
   constexpr int KH = 3, KW = 5, PH = 1, PW = 2, COT = 64, NCG = 2, TW = 256;
@@ -200,57 +253,143 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
     else mainloop(no{}, no{});
   }
 
-  // ---- epilogue: as conv_igemm.h (bias + ReLU in registers, wave-private LDS scratch, 1-KiB stores)
   constexpr int NPL = COT / EPR;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  unsigned char* scratch = smem + wave * (NPL * 1024);
-  unsigned char* yb = (unsigned char*)p.y;
-  const int yrow = p.W * p.y_wmul;
-  const int wbase = w0 + 32 * wave;
+  conv_epilogue_store<T, HT, COT>(p, acc, smem + wave * (NPL * 1024), n, h0, w0 + 32 * wave, cot, lane);
+}
+
+// ---- chunk-granular variant for 3-row tiles (6-dye profiles): a kernel-column step of a 3-row tile is only ~16 MFMAs
+// per wave, too few to pay for a barrier each, and its LDS images are small enough to double buffer BOTH operands
+// (2 x 41.6 KiB activations + 2 x 30 KiB weights = 143 KiB).  One barrier per K chunk; the whole next chunk streams
+// in while the current one (84-90 MFMAs per wave) is consumed.
+template <typename T, int HT>
+__global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p) {
+  constexpr int KH = 3, KW = 5, TAPS = 15, PH = 1, PW = 2, COT = 64, NCG = 2, TW = 256;
+  constexpr int ROWS = HT + KH - 1;
+  constexpr int QW = TW + KW - 1;
+  constexpr int EPR = RecTraits<T>::EPR;
+  constexpr int ACT_RAW = ROWS * QW * 32;
+  constexpr int ACT_BYTES = (ACT_RAW + 1023) / 1024 * 1024;
+  constexpr int W_BYTES = TAPS * COT * 32;
+  constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 8191) / 8192;       // 1-KiB pieces per wave (8 waves)
+  constexpr int BUF_BYTES = ST_ITERS * 8192;
+  static_assert(2 * BUF_BYTES <= 160 * 1024, "both operands double buffered");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_all[2 * BUF_BYTES];
+  const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  const int npt = p.N * p.nth * p.ntw;
+  const int ncot = p.cout_pad / COT;
+  const int j = blockIdx.x >> 3;
+  const int cot = j % ncot;
+  int pt = (j / ncot) * 8 + (blockIdx.x & 7);
+  if (pt >= npt) return;
+  const int tw = pt % p.ntw; pt /= p.ntw;
+  const int th = pt % p.nth;
+  const int n = pt / p.nth;
+  const int w0 = tw * TW, h0 = th * HT;
+  const int xrow = p.W * p.x_wmul;
+
+  unsigned st_off[ST_ITERS];
+  {
+    const int xrow_b = xrow * 32;
 #pragma unroll
-  for (int hh = 0; hh < HT; ++hh) {
-    const int h = h0 + hh;
-    if (h < p.H) {                                  // block-uniform
-#pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = cg * 32 + 8 * g + 4 * half;
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[hh][cg][4 * g + i];
-            if (p.bias) v[i] += p.bias[cot * COT + cl + i];
-            if (p.relu) v[i] = fmaxf(v[i], 0.f);
-          }
-          unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
-          if constexpr (sizeof(T) == 4) {
-            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
-            uint2 u;
-            u.x = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
-            u.y = (uint32_t)__builtin_bit_cast(unsigned short, b2) | ((uint32_t)__builtin_bit_cast(unsigned short, b3) << 16);
-            *(uint2*)dst = u;
-          }
-        }
+    for (int it = 0; it < ST_ITERS; ++it) {
+      const int byte = ((it * 8 + wave) * 64 + lane) * 16;
+      unsigned off = DN_OOB;
+      if (byte < ACT_RAW) {
+        const int rq = byte >> 5, pcl = (byte >> 4) & 1;
+        const int r = rq / QW, q = rq - r * QW;
+        const int h = h0 + r - PH, w = w0 + q - PW;
+        if (h >= 0 && h < p.H && w >= 0 && w < p.W) off = h * xrow_b + w * p.x_wmul * 32 + 16 * (pcl ^ ((q >> 3) & 1));
+      } else if (byte >= ACT_BYTES && byte < ACT_BYTES + W_BYTES) {
+        const int bw = byte - ACT_BYTES;
+        const int tc = bw >> 5, pcl = (bw >> 4) & 1;
+        const int tap = tc / COT, co = tc - tap * COT;
+        off = (tap * p.cout_pad + co) * 32 + 16 * (pcl ^ ((co >> 3) & 1));
       }
+      st_off[it] = off;
+    }
+  }
+
+  const unsigned char* xb = (const unsigned char*)p.x;
+  const unsigned char* wb = (const unsigned char*)p.w;
+  auto stage = [&](int ck, int buf) {
+    const int grp = ck / p.x_gplanes;
+    const int plane = ck - grp * p.x_gplanes;
+    const bool exists = ck < p.nchunk && plane < p.x_nplanes;
+    dn_srd_t srd_x = dn_make_srd(xb + (exists ? (((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow + grp) * 32 : 0));
+    dn_srd_t srd_w = dn_make_srd(wb + (exists ? ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32 : 0));
+    if (!exists) { srd_x.z = 0; srd_w.z = 0; }
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        const int vplane = cot * NPL + pl;
-        const int ygrp = vplane / p.y_gplanes;
-        const int yplane = vplane - ygrp * p.y_gplanes;
-        const int px = lane >> 1, pc = lane & 1;
-        const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
-        if (yplane < p.y_nplanes && wbase + px < p.W) {
-          const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
-                           (long)(wbase + px) * p.y_wmul + ygrp;
-          *(uint4*)(yb + rec * 32 + 16 * pc) = val;
+    for (int it = 0; it < ST_ITERS; ++it) {
+      const bool is_w = (it * 8 + wave) * 1024 >= ACT_BYTES;          // wave-uniform
+      dn_buffer_lds16(st_off[it], is_w ? srd_w : srd_x,
+                      __builtin_amdgcn_readfirstlane(smem_lds + buf * BUF_BYTES + (it * 8 + wave) * 1024));
+    }
+  };
+
+  f32x16_t acc[HT][NCG];
+#pragma unroll
+  for (int a = 0; a < HT; ++a)
+#pragma unroll
+    for (int b = 0; b < NCG; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  stage(0, 0);
+  auto mainloop = [&](auto skip_top_c, auto skip_bot_c) {
+    constexpr bool SKIP_TOP = decltype(skip_top_c)::value, SKIP_BOT = decltype(skip_bot_c)::value;
+    for (int ck = 0; ck < p.nchunk; ++ck) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // chunk ck landed for everyone; everyone left the other image
+      stage(ck + 1, (ck + 1) & 1);
+      const unsigned char* smem = smem_all + (ck & 1) * BUF_BYTES;
+#pragma unroll
+      for (int dwi = 0; dwi < KW; ++dwi) {
+        uint4 bf[ROWS];
+        const int q = 32 * wave + l31 + dwi;
+        const int boff = q * 32 + 16 * (half ^ ((q >> 3) & 1));
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) bf[r] = *(const uint4*)(smem + r * QW * 32 + boff);
+#pragma unroll
+        for (int dhi = 0; dhi < KH; ++dhi) {
+          uint4 af[NCG];
+#pragma unroll
+          for (int cg = 0; cg < NCG; ++cg) {
+            const int col = cg * 32 + l31;
+            af[cg] = *(const uint4*)(smem + ACT_BYTES + ((dhi * KW + dwi) * COT + col) * 32 + 16 * (half ^ ((col >> 3) & 1)));
+          }
+#pragma unroll
+          for (int hh = 0; hh < HT; ++hh) {
+            const int hin = hh + dhi - PH;
+            if (!(SKIP_TOP && hin < 0) && !(SKIP_BOT && hin >= HT)) {   // compile time
+#pragma unroll
+              for (int cg = 0; cg < NCG; ++cg) Mma32<T>::run(af[cg], bf[hh + dhi], acc[hh][cg]);
+            }
+          }
         }
       }
     }
+  };
+  {
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    const bool top = h0 == 0, bot = h0 + HT >= p.H;   // block-uniform
+    if (top && bot) mainloop(yes{}, yes{});
+    else if (top) mainloop(yes{}, no{});
+    else if (bot) mainloop(no{}, yes{});
+    else mainloop(no{}, no{});
   }
+
+  constexpr int NPL = COT / EPR;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  conv_epilogue_store<T, HT, COT>(p, acc, smem_all + wave * (NPL * 1024), n, h0, w0 + 32 * wave, cot, lane);
 }
 
 // the 8-wave kernel pays off once a block has enough K chunks to pipeline and the row holds whole 256-column tiles
@@ -258,14 +397,15 @@ inline bool conv_igemm8_applies(const ConvParams& p, int kh, int kw) {
   return kh == 3 && kw == 5 && p.cout_pad % 64 == 0 && p.W % 256 == 0 && p.nchunk >= 4 && p.x_wmul == 1 && p.y_wmul == 1;
 }
 
-template <typename T, int HT>
+template <typename T, int HT, bool CHUNKED = false>
 int conv_igemm8_launch(ConvParams p, hipStream_t stream) {
   p.ntw = p.W / 256;
   p.nth = (p.H + HT - 1) / HT;
   const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / 64);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
-  hipLaunchKernelGGL((conv_igemm8_kernel<T, HT>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+  if constexpr (CHUNKED) hipLaunchKernelGGL((conv_igemm8c_kernel<T, HT>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm8_kernel<T, HT>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

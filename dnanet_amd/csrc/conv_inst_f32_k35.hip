@@ -5,5 +5,6 @@ int conv_igemm_run_f32_k35(const ConvParams& p, int ht, int cot, hipStream_t s) 
   if (ht == 5 && cot == 64) return conv_igemm_launch<float, 3, 5, 5, 64>(p, s);
   if (ht == 3 && cot == 32) return conv_igemm_launch<float, 3, 5, 3, 32>(p, s);
   if (ht == 3 && cot == 64) return conv_igemm_launch<float, 3, 5, 3, 64>(p, s);
+  if (ht == 6 && cot == 32) return conv_igemm_launch<float, 3, 5, 6, 32>(p, s);
   return dn_set_error(DN_ERR_UNSUPPORTED, "conv_igemm: no instantiation for ht=%d cot=%d", ht, cot);
 }

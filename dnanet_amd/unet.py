@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import ctypes
+
 import torch
 
 from . import hip
@@ -140,13 +142,12 @@ class HipUNet(ParameterTree):
         self._eval_cache = cache
         self._eval_cache_version = self._versions()
 
-    def conv_kernel_tag(self, cout: int, h: int) -> str:
-        """Name of the conv_igemm instantiation the library dispatches to (api.hip: run_igemm)."""
+    def conv_kernel_tag(self, cin: int, cout: int, h: int, w: int) -> str:
+        """Name of the instantiation the library dispatches this convolution to (api.hip: choose_variant)."""
         kh, kw = self.kernel_size
-        cot = 64 if hip.channel_pad(cout) % 64 == 0 else 32
-        ht = 3 if ((kh, kw) == (3, 5) and h % 3 == 0 and h % 5 != 0) else 5
-        t = 'bf16' if self.dtype == BF16 else 'f32'
-        return f"conv_igemm<{t},{kh}x{kw},ht{ht},cot{cot}>"
+        buf = ctypes.create_string_buffer(96)
+        hip.check(hip.lib.dn_conv2d_variant(cin, cout, h, w, kh, kw, self.dtype, buf, len(buf)))
+        return buf.value.decode()
 
     def _conv(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1):
         if self.profile is not None and u.cin != 1:
@@ -155,7 +156,7 @@ class HipUNet(ParameterTree):
             self._conv_launch(u, entry, src, dst, n, h, w, relu)
             e1.record()
             kh, kw = self.kernel_size
-            self.profile.append((self.conv_kernel_tag(u.cout, h), 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
+            self.profile.append((self.conv_kernel_tag(u.cin, u.cout, h, w), 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
         else:
             self._conv_launch(u, entry, src, dst, n, h, w, relu)
 
