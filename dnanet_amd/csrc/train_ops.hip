@@ -128,30 +128,32 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const unsigned char*
 }
 
 // ---- BatchNorm backward ------------------------------------------------------------------------
-// reduce: S1 = sum(dz), S2 = sum(dz * xhat), dz = g * (a > 0), xhat = (y - mean) * invstd
+// reduce: S1 = sum(dz), S2 = sum(dz * xhat), dz = g * (y*scale + shift > 0), xhat = (y - mean) * invstd.
+// The ReLU mask is recomputed from y with the forward's fused scale / shift (the same fmaf the apply pass rounded to get
+// a), so the activation tensor is not read again: 2 reads here and 2 reads + 1 write in the apply pass.
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsigned char* g, int g_pt, int g_p0,
                                                                      const unsigned char* y, int y_pt, int y_p0,
-                                                                     const unsigned char* a, int a_pt, int a_p0, long N, long HW,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, long N, long HW,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ invstd, float* partial, int cpad) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
   const int plane = blockIdx.y, pc = threadIdx.x & 1;
   const int c0 = plane * EPR + pc * PN;
-  float mu[PN], is[PN];
+  float mu[PN], is[PN], sc[PN], sh[PN];
 #pragma unroll
-  for (int j = 0; j < PN; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
+  for (int j = 0; j < PN; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
   float acc[2][PN] = {};
   const long total = N * HW;
   for (long i = (long)blockIdx.x * 128 + (threadIdx.x >> 1); i < total; i += (long)gridDim.x * 128) {
     const long n = i / HW, hw = i - n * HW;
-    float fg[PN], fy[PN], fa[PN];
+    float fg[PN], fy[PN];
     Piece<T>::unpack(*(const uint4*)(g + rec_off(g_pt, g_p0 + plane, n, hw, HW) + 16 * pc), fg);
     Piece<T>::unpack(*(const uint4*)(y + rec_off(y_pt, y_p0 + plane, n, hw, HW) + 16 * pc), fy);
-    Piece<T>::unpack(*(const uint4*)(a + rec_off(a_pt, a_p0 + plane, n, hw, HW) + 16 * pc), fa);
 #pragma unroll
     for (int j = 0; j < PN; ++j) {
-      const float dz = fa[j] > 0.f ? fg[j] : 0.f;
+      const float dz = fmaf(fy[j], sc[j], sh[j]) > 0.f ? fg[j] : 0.f;   // the forward's own pre-ReLU value
       acc[0][j] += dz;
       acc[1][j] = fmaf(dz, (fy[j] - mu[j]) * is[j], acc[1][j]);
     }
@@ -176,7 +178,8 @@ __global__ void bn_bwd_finalize_kernel(const float* partial, int nblk, int cpad,
 // apply (in place on g): dy = s * (dz - c1 - xhat * c2)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(unsigned char* g, int g_pt, int g_p0, const unsigned char* y, int y_pt,
-                                                           int y_p0, const unsigned char* a, int a_pt, int a_p0, int nplanes,
+                                                           int y_p0, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int nplanes,
                                                            long N, long HW, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            int cpad) {
@@ -189,15 +192,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(unsigned char* g, int
     const int pl = (int)(r % nplanes);
     const long n = r / nplanes;
     unsigned char* gp = g + rec_off(g_pt, g_p0 + pl, n, hw, HW) + 16 * pc;
-    float fg[PN], fy[PN], fa[PN];
+    float fg[PN], fy[PN];
     Piece<T>::unpack(*(const uint4*)gp, fg);
     Piece<T>::unpack(*(const uint4*)(y + rec_off(y_pt, y_p0 + pl, n, hw, HW) + 16 * pc), fy);
-    Piece<T>::unpack(*(const uint4*)(a + rec_off(a_pt, a_p0 + pl, n, hw, HW) + 16 * pc), fa);
     const int c0 = pl * EPR + pc * PN;
 #pragma unroll
     for (int j = 0; j < PN; ++j) {
       const int c = c0 + j;
-      const float dz = fa[j] > 0.f ? fg[j] : 0.f;
+      const float dz = fmaf(fy[j], scale[c], shift[c]) > 0.f ? fg[j] : 0.f;
       const float xhat = (fy[j] - mean[c]) * invstd[c];
       fg[j] = coef[c] * (dz - coef[cpad + c] - xhat * coef[2 * cpad + c]);
     }
@@ -464,17 +466,18 @@ int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const flo
   return DN_OK;
 }
 
-int dn_bn_train_backward(dn_tensor g, dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* mean,
-                         const float* invstd, float* dgamma, float* dbeta, float* coef, float* partial, int dtype,
-                         void* stream) {
-  DN_CHECK_ARG(g.base && y.base && a.base && gamma && mean && invstd && dgamma && dbeta && coef && partial, "dn_bn_train_backward: null pointer");
-  DN_CHECK_ARG(g.channels == y.channels && y.channels == a.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_backward: bad shape");
+int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                         float* partial, int dtype, void* stream) {
+  DN_CHECK_ARG(g.base && y.base && scale && shift && gamma && mean && invstd && dgamma && dbeta && coef && partial,
+               "dn_bn_train_backward: null pointer");
+  DN_CHECK_ARG(g.channels == y.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_backward: bad shape");
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
   const int nblk = red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
 #define ARGS_R (const unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)y.base, y.planes_total, y.plane0, \
-               (const unsigned char*)a.base, a.planes_total, a.plane0, (long)N, HW, mean, invstd, partial, cpad
+               scale, shift, (long)N, HW, mean, invstd, partial, cpad
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
@@ -486,7 +489,7 @@ int dn_bn_train_backward(dn_tensor g, dn_tensor y, dn_tensor a, int N, int H, in
   DN_LAUNCH_CHECK();
   const long total = (long)N * nplanes * HW * 2;
 #define ARGS_A (unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)y.base, y.planes_total, y.plane0, \
-               (const unsigned char*)a.base, a.planes_total, a.plane0, nplanes, (long)N, HW, mean, invstd, coef, cpad
+               scale, shift, nplanes, (long)N, HW, mean, invstd, coef, cpad
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), 0, s, ARGS_A),
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, ARGS_A),

@@ -288,7 +288,8 @@ class HipUNet(ParameterTree):
             hip.ptr(self.tensor(u.bn + ".running_mean")), hip.ptr(self.tensor(u.bn + ".running_var")), BN_MOMENTUM, BN_EPS,
             hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift), hip.ptr(ws["partial"]), self.dtype,
             hip.stream_ptr()))
-        self._saved[u.conv] = {"y": y, "a": dst, "src": src, "mean": mean, "invstd": invstd, "vec": vec, "n": n, "h": h, "w": w}
+        self._saved[u.conv] = {"y": y, "a": dst, "src": src, "mean": mean, "invstd": invstd, "scale": scale, "shift": shift,
+                               "vec": vec, "n": n, "h": h, "w": w}
 
     def forward_train(self, x: torch.Tensor) -> torch.Tensor:
         """Train-mode forward (batch statistics, running-stat update); keeps activations for backward()."""
@@ -364,7 +365,8 @@ class HipUNet(ParameterTree):
         n, h, w = sv["n"], sv["h"], sv["w"]
         kh, kw = self.kernel_size
         hip.check(hip.lib.dn_bn_train_backward(
-            g, sv["y"].ref(u.cout), sv["a"], n, h, w, hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(sv["mean"]),
+            g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
+            hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(sv["mean"]),
             hip.ptr(sv["invstd"]), hip.ptr(self.grad(u.bn + ".weight")), hip.ptr(self.grad(u.bn + ".bias")),
             hip.ptr(ws["coef"]), hip.ptr(ws["partial"]), self.dtype, hip.stream_ptr()))
         # the conv bias feeds a BatchNorm: its gradient is identically zero, the arena entry stays 0

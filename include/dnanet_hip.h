@@ -98,10 +98,12 @@ int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const flo
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                         float* scale, float* shift, float* partial, int dtype, void* stream);
 /* Backward of ReLU + BatchNorm2d (autograd of the above, trainable_unet.py:342): on entry g = dL/da,
- * on exit g = dL/dy (in place); dgamma/dbeta are written ([C]); coef: 3*dn_channel_pad(C) scratch. */
-int dn_bn_train_backward(dn_tensor g, dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* mean,
-                         const float* invstd, float* dgamma, float* dbeta, float* coef, float* partial, int dtype,
-                         void* stream);
+ * on exit g = dL/dy (in place); dgamma/dbeta are written ([C]); coef: 3*dn_channel_pad(C) scratch.
+ * scale/shift/mean/invstd are the vectors dn_bn_train_forward saved: the ReLU mask is recomputed as
+ * y*scale + shift > 0, so the activation tensor is not read. */
+int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                         float* partial, int dtype, void* stream);
 /* Backward of nn.MaxPool2d((1,2)) (unet_architecture.py:37) fused with the skip-connection add:
  * g = dskip (nullable .base) + route(dpool) to the first maximal element of every pair of x. */
 int dn_maxpool_1x2_backward(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, int N, int H, int Wout, int dtype,

@@ -281,7 +281,8 @@ def test_batchnorm_train_forward_backward(gpu_device, dtype):
     (a_ref * (a_store > 0).float()).backward(gq) if False else a_ref.backward(gq * ((a_store > 0) == (a_ref > 0)).float())
     dgam, dbet = torch.empty(c, device=dev), torch.empty(c, device=dev)
     coef = torch.empty(3 * cp, device=dev)
-    hip.check(hip.lib.dn_bn_train_backward(gb.ref(c), yb.ref(c), ab.ref(c), n, h, w, hip.ptr(gd), hip.ptr(mean), hip.ptr(invstd),
+    hip.check(hip.lib.dn_bn_train_backward(gb.ref(c), yb.ref(c), hip.ptr(scale), hip.ptr(shift), n, h, w, hip.ptr(gd),
+                                           hip.ptr(mean), hip.ptr(invstd),
                                            hip.ptr(dgam), hip.ptr(dbet), hip.ptr(coef), hip.ptr(part), dtype, hip.stream_ptr()))
     torch.cuda.synchronize()
     gt = 2e-5 if dtype == 0 else 2e-2
