@@ -63,19 +63,38 @@ __device__ __forceinline__ double wave_sum_partials(const float* partial, int nb
 }
 
 // ---- BatchNorm statistics: sum(y), sum(y^2) --------------------------------------------------
+// Reduction work split: a plane of one image is a contiguous run of 2*H*W 16-byte pieces; it is cut into segments of
+// RED_SEG pieces and the (image, segment) units are dealt round-robin to the blocks of a plane.  A thread reads four
+// pieces 256 apart per step (independent loads in flight: a single dependent load per thread left HBM at ~4 TB/s);
+// its piece parity, hence its channels, is fixed (threadIdx.x & 1).
+constexpr int RED_SEG = 4096;
+
 template <typename T>
-__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned char* y, int planes_total, int plane0, long N,
-                                                                long HW, float* partial, int cpad) {
+__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned char* y, int planes_total, int plane0, int N,
+                                                                int npieces, float* partial, int cpad) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
-  const int plane = blockIdx.y, pc = threadIdx.x & 1;
+  const int plane = blockIdx.y;
   float acc[2][PN] = {};
-  const long total = N * HW;
-  for (long i = (long)blockIdx.x * 128 + (threadIdx.x >> 1); i < total; i += (long)gridDim.x * 128) {
-    const long n = i / HW, hw = i - n * HW;
-    float f[PN];
-    Piece<T>::unpack(*(const uint4*)(y + rec_off(planes_total, plane0 + plane, n, hw, HW) + 16 * pc), f);
+  const int nseg = (npieces + RED_SEG - 1) / RED_SEG;
+  for (int u = blockIdx.x; u < N * nseg; u += gridDim.x) {
+    const int n = u / nseg, seg = u - n * nseg;
+    const unsigned char* base = y + ((long)n * planes_total + plane0 + plane) * npieces * 16;
+    const int iend = min(npieces, (seg + 1) * RED_SEG);
+    for (int i = seg * RED_SEG + threadIdx.x; i < iend; i += 4 * RED_THREADS) {
+      uint4 v[4];
 #pragma unroll
-    for (int j = 0; j < PN; ++j) { acc[0][j] += f[j]; acc[1][j] = fmaf(f[j], f[j], acc[1][j]); }
+      for (int k = 0; k < 4; ++k) {
+        const int ii = i + k * RED_THREADS;
+        v[k] = ii < iend ? *(const uint4*)(base + (long)ii * 16) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f[PN];
+        Piece<T>::unpack(v[k], f);
+#pragma unroll
+        for (int j = 0; j < PN; ++j) { acc[0][j] += f[j]; acc[1][j] = fmaf(f[j], f[j], acc[1][j]); }
+      }
+    }
   }
   block_reduce_store<2, PN>(acc, partial, cpad, plane, EPR);
 }
@@ -105,25 +124,27 @@ __global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int
   }
 }
 
-// a = relu(y * scale + shift)
+// a = relu(y * scale + shift).  Grid (x, plane, image): a plane of one image is a contiguous run of 16-byte pieces, so the
+// index is 32-bit and there is no division in the loop.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const unsigned char* y, int y_pt, int y_p0, unsigned char* a,
-                                                            int a_pt, int a_p0, int nplanes, long N, long HW,
+                                                            int a_pt, int a_p0, int npieces,
                                                             const float* __restrict__ scale, const float* __restrict__ shift) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
-  const long total = N * nplanes * HW * 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int pc = (int)(i & 1);
-    long r = i >> 1;
-    const long hw = r % HW; r /= HW;
-    const int pl = (int)(r % nplanes);
-    const long n = r / nplanes;
-    float f[PN];
-    Piece<T>::unpack(*(const uint4*)(y + rec_off(y_pt, y_p0 + pl, n, hw, HW) + 16 * pc), f);
-    const int c0 = pl * EPR + pc * PN;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const unsigned char* yp = y + ((long)n * y_pt + y_p0 + pl) * npieces * 16;
+  unsigned char* ap = a + ((long)n * a_pt + a_p0 + pl) * npieces * 16;
+  // the stride is even, so a thread keeps its piece parity = its channels: coefficients live in registers
+  const int c0 = pl * EPR + (threadIdx.x & 1) * PN;
+  float sc[PN], sh[PN];
 #pragma unroll
-    for (int j = 0; j < PN; ++j) f[j] = fmaxf(fmaf(f[j], scale[c0 + j], shift[c0 + j]), 0.f);
-    *(uint4*)(a + rec_off(a_pt, a_p0 + pl, n, hw, HW) + 16 * pc) = Piece<T>::pack(f);
+  for (int j = 0; j < PN; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += gridDim.x * blockDim.x) {
+    float f[PN];
+    Piece<T>::unpack(*(const uint4*)(yp + (long)i * 16), f);
+#pragma unroll
+    for (int j = 0; j < PN; ++j) f[j] = fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f);
+    *(uint4*)(ap + (long)i * 16) = Piece<T>::pack(f);
   }
 }
 
@@ -135,7 +156,7 @@ template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsigned char* g, int g_pt, int g_p0,
                                                                      const unsigned char* y, int y_pt, int y_p0,
                                                                      const float* __restrict__ scale,
-                                                                     const float* __restrict__ shift, long N, long HW,
+                                                                     const float* __restrict__ shift, int N, int npieces,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ invstd, float* partial, int cpad) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
@@ -145,17 +166,33 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsign
 #pragma unroll
   for (int j = 0; j < PN; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
   float acc[2][PN] = {};
-  const long total = N * HW;
-  for (long i = (long)blockIdx.x * 128 + (threadIdx.x >> 1); i < total; i += (long)gridDim.x * 128) {
-    const long n = i / HW, hw = i - n * HW;
-    float fg[PN], fy[PN];
-    Piece<T>::unpack(*(const uint4*)(g + rec_off(g_pt, g_p0 + plane, n, hw, HW) + 16 * pc), fg);
-    Piece<T>::unpack(*(const uint4*)(y + rec_off(y_pt, y_p0 + plane, n, hw, HW) + 16 * pc), fy);
+  const int nseg = (npieces + RED_SEG - 1) / RED_SEG;
+  for (int u = blockIdx.x; u < N * nseg; u += gridDim.x) {
+    const int n = u / nseg, seg = u - n * nseg;
+    const unsigned char* gbase = g + ((long)n * g_pt + g_p0 + plane) * npieces * 16;
+    const unsigned char* ybase = y + ((long)n * y_pt + y_p0 + plane) * npieces * 16;
+    const int iend = min(npieces, (seg + 1) * RED_SEG);
+    for (int i = seg * RED_SEG + threadIdx.x; i < iend; i += 2 * RED_THREADS) {
+      uint4 vg[2], vy[2];
 #pragma unroll
-    for (int j = 0; j < PN; ++j) {
-      const float dz = fmaf(fy[j], sc[j], sh[j]) > 0.f ? fg[j] : 0.f;   // the forward's own pre-ReLU value
-      acc[0][j] += dz;
-      acc[1][j] = fmaf(dz, (fy[j] - mu[j]) * is[j], acc[1][j]);
+      for (int k = 0; k < 2; ++k) {
+        const int ii = i + k * RED_THREADS;
+        const bool in = ii < iend;
+        vg[k] = in ? *(const uint4*)(gbase + (long)ii * 16) : make_uint4(0, 0, 0, 0);   // g = 0 adds nothing
+        vy[k] = in ? *(const uint4*)(ybase + (long)ii * 16) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float fg[PN], fy[PN];
+        Piece<T>::unpack(vg[k], fg);
+        Piece<T>::unpack(vy[k], fy);
+#pragma unroll
+        for (int j = 0; j < PN; ++j) {
+          const float dz = fmaf(fy[j], sc[j], sh[j]) > 0.f ? fg[j] : 0.f;   // the forward's own pre-ReLU value
+          acc[0][j] += dz;
+          acc[1][j] = fmaf(dz, (fy[j] - mu[j]) * is[j], acc[1][j]);
+        }
+      }
     }
   }
   block_reduce_store<2, PN>(acc, partial, cpad, plane, EPR);
@@ -175,33 +212,36 @@ __global__ void bn_bwd_finalize_kernel(const float* partial, int nblk, int cpad,
   coef[2 * cpad + c] = (float)(s2 / count);  // mean(dz * xhat)
 }
 
-// apply (in place on g): dy = s * (dz - c1 - xhat * c2)
+// apply (in place on g): dy = s * (dz - c1 - xhat * c2).  Grid (x, plane, image) as bn_apply_relu_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(unsigned char* g, int g_pt, int g_p0, const unsigned char* y, int y_pt,
                                                            int y_p0, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, int nplanes,
-                                                           long N, long HW, const float* __restrict__ mean,
+                                                           const float* __restrict__ shift, int npieces,
+                                                           const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            int cpad) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
-  const long total = N * nplanes * HW * 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int pc = (int)(i & 1);
-    long r = i >> 1;
-    const long hw = r % HW; r /= HW;
-    const int pl = (int)(r % nplanes);
-    const long n = r / nplanes;
-    unsigned char* gp = g + rec_off(g_pt, g_p0 + pl, n, hw, HW) + 16 * pc;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  unsigned char* gbase = g + ((long)n * g_pt + g_p0 + pl) * npieces * 16;
+  const unsigned char* ybase = y + ((long)n * y_pt + y_p0 + pl) * npieces * 16;
+  const int c0 = pl * EPR + (threadIdx.x & 1) * PN;   // fixed per thread (even stride): coefficients in registers
+  float sc[PN], sh[PN], mu[PN], is[PN], k0[PN], k1[PN], k2[PN];
+#pragma unroll
+  for (int j = 0; j < PN; ++j) {
+    const int c = c0 + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+    k0[j] = coef[c]; k1[j] = coef[cpad + c]; k2[j] = coef[2 * cpad + c];
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npieces; i += gridDim.x * blockDim.x) {
+    unsigned char* gp = gbase + (long)i * 16;
     float fg[PN], fy[PN];
     Piece<T>::unpack(*(const uint4*)gp, fg);
-    Piece<T>::unpack(*(const uint4*)(y + rec_off(y_pt, y_p0 + pl, n, hw, HW) + 16 * pc), fy);
-    const int c0 = pl * EPR + pc * PN;
+    Piece<T>::unpack(*(const uint4*)(ybase + (long)i * 16), fy);
 #pragma unroll
     for (int j = 0; j < PN; ++j) {
-      const int c = c0 + j;
-      const float dz = fmaf(fy[j], scale[c], shift[c]) > 0.f ? fg[j] : 0.f;
-      const float xhat = (fy[j] - mean[c]) * invstd[c];
-      fg[j] = coef[c] * (dz - coef[cpad + c] - xhat * coef[2 * cpad + c]);
+      const float dz = fmaf(fy[j], sc[j], sh[j]) > 0.f ? fg[j] : 0.f;
+      const float xhat = (fy[j] - mu[j]) * is[j];
+      fg[j] = k0[j] * (dz - k1[j] - xhat * k2[j]);
     }
     *(uint4*)gp = Piece<T>::pack(fg);
   }
@@ -277,8 +317,11 @@ __global__ __launch_bounds__(RED_THREADS) void channel_sum_kernel(const unsigned
   const int plane = blockIdx.y, pc = threadIdx.x & 1;
   float acc[1][PN] = {};
   const long total = N * HW;
-  for (long i = (long)blockIdx.x * 128 + (threadIdx.x >> 1); i < total; i += (long)gridDim.x * 128) {
-    const long n = i / HW, hw = i - n * HW;
+  const long step = (long)gridDim.x * 128;
+  long i = (long)blockIdx.x * 128 + (threadIdx.x >> 1);
+  long n = i / HW, hw = i - n * HW;          // one division per thread; then carried along
+  for (; i < total; i += step, hw += step) {
+    while (hw >= HW) { hw -= HW; ++n; }
     float f[PN];
     Piece<T>::unpack(*(const uint4*)(x + rec_off(x_pt, x_p0 + plane, n, hw, HW) + 16 * pc), f);
     const float s = pixscale ? pixscale[i] : 1.f;
@@ -447,20 +490,22 @@ int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const flo
   DN_CHECK_ARG(y.channels == a.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_forward: bad shape");
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
+  DN_CHECK_ARG(HW * 2 < (1L << 31) && N < 65536 && nplanes < 65536, "dn_bn_train_forward: plane too large for the launch grid");
   const int nblk = red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
   DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(bn_stats_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (long)N, HW, partial, cpad),
-    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (long)N, HW, partial, cpad),
+    hipLaunchKernelGGL(bn_stats_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), partial, cpad),
+    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), partial, cpad),
     "dn_bn_train_forward");
   DN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   DN_LAUNCH_CHECK();
-  const long total = (long)N * nplanes * HW * 2;
+  const int npieces = (int)(HW * 2);
+  const dim3 egrid(std::min((npieces + 1023) / 1024, 64), nplanes, N);   // ~4 pieces per thread
   DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(bn_apply_relu_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (unsigned char*)a.base, a.planes_total, a.plane0, nplanes, (long)N, HW, scale, shift),
-    hipLaunchKernelGGL(bn_apply_relu_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (unsigned char*)a.base, a.planes_total, a.plane0, nplanes, (long)N, HW, scale, shift),
+    hipLaunchKernelGGL(bn_apply_relu_kernel<__bf16>, egrid, dim3(256), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (unsigned char*)a.base, a.planes_total, a.plane0, npieces, scale, shift),
+    hipLaunchKernelGGL(bn_apply_relu_kernel<float>, egrid, dim3(256), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (unsigned char*)a.base, a.planes_total, a.plane0, npieces, scale, shift),
     "dn_bn_train_forward");
   DN_LAUNCH_CHECK();
   return DN_OK;
@@ -474,10 +519,11 @@ int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const flo
   DN_CHECK_ARG(g.channels == y.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_backward: bad shape");
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
+  DN_CHECK_ARG(HW * 2 < (1L << 31) && N < 65536 && nplanes < 65536, "dn_bn_train_backward: plane too large for the launch grid");
   const int nblk = red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
 #define ARGS_R (const unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)y.base, y.planes_total, y.plane0, \
-               scale, shift, (long)N, HW, mean, invstd, partial, cpad
+               scale, shift, N, (int)(HW * 2), mean, invstd, partial, cpad
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
@@ -487,12 +533,13 @@ int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const flo
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma,
                      invstd, dgamma, dbeta, coef);
   DN_LAUNCH_CHECK();
-  const long total = (long)N * nplanes * HW * 2;
+  const int npieces = (int)(HW * 2);
+  const dim3 egrid(std::min((npieces + 1023) / 1024, 64), nplanes, N);
 #define ARGS_A (unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)y.base, y.planes_total, y.plane0, \
-               scale, shift, nplanes, (long)N, HW, mean, invstd, coef, cpad
+               scale, shift, npieces, mean, invstd, coef, cpad
   DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), 0, s, ARGS_A),
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, ARGS_A),
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, egrid, dim3(256), 0, s, ARGS_A),
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, egrid, dim3(256), 0, s, ARGS_A),
     "dn_bn_train_backward");
 #undef ARGS_A
   DN_LAUNCH_CHECK();
