@@ -14,9 +14,16 @@ from typing import Any, Iterable, Mapping, MutableMapping, Optional, Union
 
 import yaml
 
+from functools import partial
+
+from .data import ArrayDataset, NpyDirDataset, SyntheticDataset
+from .metrics import METRICS
 from .model import DNANet_UNet, Model
 
 MODELS = {"model": {"unet": DNANet_UNet}}
+# The reference registers its .hid reader here (``config_io.py:28``); parsing .hid files is outside the hot path, so
+# the datasets of this build are array-backed.  A reference ``HIDDataset`` can be passed to the model API directly.
+DATASETS = {"dataset": {"npy": NpyDirDataset, "synthetic": SyntheticDataset}}
 
 
 def get_config_path(name: str, kind: Optional[str] = None, root="." ) -> Path:
@@ -71,3 +78,41 @@ def load_model(source) -> Model:
         model.load(source)
         return model
     return parse_config(load_config(source, kind="models"), MODELS)["model"]
+
+
+def load_dataset(source) -> ArrayDataset:
+    """``config/data/<name>.yaml`` -> dataset (``config_io.py:107-113``)."""
+    return parse_config(load_config(source, kind="data"), DATASETS)["dataset"]
+
+
+def load_evaluation_config(source) -> MutableMapping[str, Any]:
+    """Metric name (+ ``_<kwarg>_<value>`` when it has arguments) -> callable(images=, predictions=)
+    (``config_io.py:82-96``)."""
+    config = load_config(source, kind="evaluation")
+    metrics = {}
+    for entry in config["evaluation"]["metrics"]:
+        entry = dict(entry)
+        name = entry.pop("name")
+        if name not in METRICS:
+            raise KeyError(f"Unknown metric {name!r}; available: {sorted(METRICS)}")
+        label = name + (f"_{next(iter(entry))}_{entry[next(iter(entry))]}" if entry else "")
+        metrics[label] = partial(METRICS[name], **entry)
+    return metrics
+
+
+def dump_config(path, data_config, model_config, training_config=None, validation_config=None, dataset=None, model=None):
+    """Write the configs a run was started with into its output directory so it can be retraced
+    (``config_io.py:173-230``); returns what was written."""
+    out = {"data": load_config(data_config, kind="data"), "model": load_config(model_config, kind="models")}
+    if training_config:
+        out["training"] = load_config(training_config, kind="training")
+    if validation_config is not None:
+        try:
+            out["validation"] = float(validation_config)
+        except (TypeError, ValueError):
+            out["validation"] = load_config(validation_config, kind="data")
+    if dataset is not None:
+        out["n_images"] = len(dataset)
+    with open(path, "w") as f:
+        yaml.safe_dump(out, f, sort_keys=False)
+    return out

@@ -8,6 +8,9 @@ the reference's own ``HIDImage`` / ``HIDDataset`` objects work unchanged.
 """
 from __future__ import annotations
 
+import glob
+import os
+import random
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
 from itertools import islice
@@ -104,3 +107,89 @@ def chunks(iterable: Iterable, chunk_size: int, skip_remainder: bool = False) ->
         if skip_remainder and len(batch) < chunk_size:
             return
         yield batch
+
+
+class ArrayDataset(Sequence):
+    """An in-memory sequence of images with the reference's split contract (``DNAnet/data/data_models/base.py:69-111``,
+    ``DNAnet/data/split.py:8-40``): ``split(fraction, seed)`` shuffles with ``random.seed(seed)`` and cuts at
+    ``int(len * fraction)``; ``split_k_fold(k, seed)`` deals the shuffled images into k folds whose sizes differ by at
+    most one and returns (train, test) pairs, fold i being the test set of pair i."""
+
+    def __init__(self, data: Sequence = (), shuffle: bool = False):
+        self._data = list(data)
+        self.shuffle = shuffle
+
+    def __len__(self) -> int:
+        return len(self._data)
+
+    def __getitem__(self, index):
+        return self._data[index]
+
+    def __iter__(self):
+        if self.shuffle:
+            return iter(random.sample(self._data, len(self._data)))
+        return iter(self._data)
+
+    def split(self, fraction: float, seed: Optional[float] = None) -> Tuple["ArrayDataset", "ArrayDataset"]:
+        if not 0 < fraction < 1:
+            raise ValueError(f"Fraction should be between 0 and 1, got {fraction}.")
+        random.seed(seed)
+        order = random.sample(self._data, len(self._data))
+        cut = int(len(order) * fraction)
+        return ArrayDataset(order[:cut], self.shuffle), ArrayDataset(order[cut:], self.shuffle)
+
+    def split_k_fold(self, n_folds: int, seed: Optional[float] = None) -> List[Tuple["ArrayDataset", "ArrayDataset"]]:
+        if n_folds < 2 or n_folds > len(self._data):
+            raise ValueError(f"Cannot make {n_folds} folds out of {len(self._data)} images.")
+        random.seed(seed)
+        order = random.sample(self._data, len(self._data))
+        base, extra = divmod(len(order), n_folds)
+        folds = [order[i * base:(i + 1) * base] for i in range(n_folds)]
+        for k, item in enumerate(order[n_folds * base:]):      # the remainder goes one each to the first folds
+            folds[k % n_folds].append(item)
+        assert extra == len(order) - n_folds * base
+        for fold in folds:
+            random.shuffle(fold)
+        pairs = []
+        for i in range(n_folds):
+            train = [im for j, fold in enumerate(folds) if j != i for im in fold]
+            pairs.append((ArrayDataset(train, self.shuffle), ArrayDataset(folds[i], self.shuffle)))
+        return pairs
+
+
+class NpyDirDataset(ArrayDataset):
+    """Profiles stored as ``<name>.npy`` (H, W, 1) RFU + ``<name>_annotation.npy`` (H, W, 1) mask, the layout of the
+    reference's ``tests/resources/profiles/RD``.  Stands in for ``HIDDataset`` (``.hid`` parsing is outside the path);
+    ``panel`` / ``scaler`` are optional and only needed by the allele caller."""
+
+    def __init__(self, root: str, panel: Optional[str] = None, scaler: Optional[Sequence[float]] = None,
+                 limit: Optional[int] = None, shuffle: bool = False):
+        if not os.path.isdir(root):
+            raise FileNotFoundError(f"Dataset directory {root} does not exist.")
+        pan = Panel(panel) if panel else None
+        images = []
+        for path in sorted(glob.glob(os.path.join(root, "*.npy"))):
+            if path.endswith("_annotation.npy"):
+                continue
+            rfu = np.load(path)
+            ann_path = path[:-4] + "_annotation.npy"
+            ann = Annotation(image=np.load(ann_path).astype(np.int8)) if os.path.isfile(ann_path) else None
+            sc = np.linspace(scaler[0], scaler[1], rfu.shape[1]) if scaler is not None else None
+            images.append(ArrayImage(data=rfu.astype(np.int16), annotation=ann, path=path, meta={}, _scaler=sc, _panel=pan))
+            if limit and len(images) >= limit:
+                break
+        if not images:
+            raise FileNotFoundError(f"No .npy profiles found in {root}.")
+        super().__init__(images, shuffle)
+
+
+class SyntheticDataset(ArrayDataset):
+    """``n`` synthetic electropherograms of SURVEY 8d's generator (``dnanet_amd/synthetic.py``)."""
+
+    def __init__(self, n: int, rows: int = 5, width: int = 4096, seed: int = 1234, shuffle: bool = False):
+        from .synthetic import make_batch
+        x, t = make_batch(n, rows, width, seed=seed, unique=n)
+        images = [ArrayImage(data=np.moveaxis(x[i], 0, -1).astype(np.int16),
+                             annotation=Annotation(image=np.moveaxis(t[i], 0, -1).astype(np.int8)),
+                             path=f"synthetic://{seed}/{i}", meta={}) for i in range(n)]
+        super().__init__(images, shuffle)

@@ -1,0 +1,61 @@
+"""Train a model on a dataset: ``python train.py -d <data> -m <model> -t <training> [-s F] [-o DIR] [-v CFG|F] [-c DIR] [-rs N]``.
+
+Same flags and order of operations as the reference's ``train.py`` (load model, optional checkpoint, load + split
+dataset, ``fit``, ``save``, dump the config next to the weights); runs on ``dnanet_amd``.
+"""
+import argparse
+
+from dnanet_amd.cli import LOGGER, split_validation, start_run
+from dnanet_amd.config_io import dump_config, load_dataset, load_model, load_training_config
+from dnanet_amd.model import TrainableModel
+
+
+def run(data_config, model_config, training_config, split=None, output_dir=None, validation_config=None,
+        checkpoint_dir=None, seed=None):
+    output_dir = start_run("train", output_dir, "log_training.txt")
+    LOGGER.info("Loading model...")
+    model = load_model(model_config)
+    if not isinstance(model, TrainableModel):
+        raise ValueError(f"Model {model} is not trainable.")
+    if checkpoint_dir:
+        model.load(checkpoint_dir)
+        LOGGER.info("Loaded previous model checkpoint from %s", checkpoint_dir)
+    else:
+        LOGGER.info("Will start training from scratch")
+
+    LOGGER.info("Loading dataset...")
+    dataset = load_dataset(data_config)
+    if split:
+        LOGGER.info("Splitting dataset, using %s%% for training", split * 100)
+        dataset, _ = dataset.split(split, seed=seed)
+    dataset, validation_set = split_validation(dataset, validation_config)
+
+    kwargs = load_training_config(training_config)
+    kwargs.update({"validation_set": validation_set, "checkpoint_dir": output_dir})
+    LOGGER.info("Starting training...")
+    try:
+        model.fit(dataset, **kwargs)
+    except KeyboardInterrupt:
+        LOGGER.info("Training interrupted!")
+    model.save(output_dir)
+    LOGGER.info("Saved model to %s", output_dir)
+    dump_config(f"{output_dir}/config.yaml", data_config, model_config, training_config, validation_config, dataset, model)
+    return output_dir
+
+
+def get_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    p.add_argument("-d", "--data-config", required=True, help="data config: path to a .yaml or a name under config/data/")
+    p.add_argument("-m", "--model-config", required=True, help="model config: path or name under config/models/")
+    p.add_argument("-t", "--training-config", required=True, help="fit() keyword arguments: path or name under config/training/")
+    p.add_argument("-s", "--split", type=float, default=None, help="fraction in (0, 1) of the dataset to train on")
+    p.add_argument("-o", "--output-dir", default=None, help="directory the trained model is saved to")
+    p.add_argument("-v", "--validation-config", default=None,
+                   help="data config of a validation set, or the fraction of the training set to hold out")
+    p.add_argument("-c", "--checkpoint-dir", default=None, help="resume from the checkpoint in this directory")
+    p.add_argument("-rs", "--seed", type=int, default=None, help="seed of the split (use the same one when evaluating)")
+    return p
+
+
+if __name__ == "__main__":
+    run(**vars(get_parser().parse_args()))
