@@ -6,6 +6,10 @@ run's mean base pair (``:90``) selects the panel allele with the nearest base pa
 (``:122-123``, first-listed wins a tie); the allele's height is the highest RFU seen in any of its runs
 (``:94-98``).  This implementation finds runs with one vectorised edge detection per dye and the nearest
 allele by binary search on the dye's sorted base-pair table instead of Python loops over pixels/alleles.
+
+``call_alleles_batch`` is the batched device path used by ``predict_batch``: the run finding, mean base pair, nearest
+allele and peak height of every run of every profile are computed by ``dn_call_alleles`` on the probability maps while
+they are still in HBM; the host only turns the small per-allele tables into ``Marker`` objects.
 """
 from __future__ import annotations
 
@@ -93,3 +97,72 @@ class NearestBasePairCaller:
                 rfus[key] = int(max(rfus.get(key, 0), rfu_row[a:b].max()))
         return [Marker(dye, marker_name, alleles=[Allele(name=a, height=rfus[(marker_name, a)]) for a in alleles])
                 for (dye, marker_name), alleles in loci.items()]
+
+    # ---- batched device path ---------------------------------------------------------------------
+    def _device_tables(self, panel: Panel, n_rows: int, device):
+        """Concatenated per-dye tables of a panel on the device: (bp, order, offsets, amax)."""
+        import torch
+        cache = self.__dict__.setdefault("_dev_tables", {})
+        key = (id(panel), n_rows, str(device))
+        if key not in cache:
+            bps, orders, offs = [], [], [0]
+            for dye in range(n_rows):
+                if dye in panel.dye_bp_to_allele_mapping:
+                    t = self._table(panel, dye)
+                    bps.append(t.bps); orders.append(np.asarray(t.order, dtype=np.int32))
+                    offs.append(offs[-1] + len(t.bps))
+                else:
+                    offs.append(offs[-1])
+            amax = max(1, max(b - a for a, b in zip(offs[:-1], offs[1:])))
+            cache[key] = (torch.from_numpy(np.concatenate(bps) if bps else np.zeros(1)).to(device),
+                          torch.from_numpy(np.concatenate(orders) if orders else np.zeros(1, np.int32)).to(device),
+                          torch.tensor(offs, dtype=torch.int32, device=device), amax)
+        return cache[key]
+
+    def call_alleles_batch(self, images, predictions, probs, rfu):
+        """``call_alleles`` for a whole batch.  ``probs`` / ``rfu``: (N,1,H,W) fp32 device tensors (probabilities of this
+        batch, the raw inputs they were computed from).  Profiles are grouped by panel; every group is one launch."""
+        import torch
+        from . import hip
+        n, _, h, w = probs.shape
+        groups: Dict[int, List[int]] = {}
+        for i, im in enumerate(images):
+            groups.setdefault(id(im._panel), []).append(i)
+        for idx in groups.values():
+            panel = images[idx[0]]._panel
+            tb, to, toff, amax = self._device_tables(panel, h, probs.device)
+            whole = len(idx) == n
+            p_sel = probs if whole else probs[idx].contiguous()
+            x_sel = rfu if whole else rfu[idx].contiguous()
+            scalers = [images[i]._scaler for i in idx]
+            shared = all(sc is scalers[0] for sc in scalers)
+            sc_np = np.asarray(scalers[0], dtype=np.float64).reshape(1, -1) if shared else \
+                np.stack([np.asarray(sc, dtype=np.float64).reshape(-1) for sc in scalers])
+            if sc_np.shape[1] != w:
+                raise ValueError(f"scaler has {sc_np.shape[1]} entries for {w} scan columns")
+            sc_dev = torch.from_numpy(np.ascontiguousarray(sc_np)).to(probs.device)
+            out = torch.empty((2, len(idx), h, amax), dtype=torch.int32, device=probs.device)
+            hip.check(hip.lib.dn_call_alleles(hip.ptr(p_sel), hip.ptr(x_sel), hip.ptr(sc_dev), 0 if shared else w, hip.ptr(tb),
+                                              hip.ptr(to), hip.ptr(toff), len(idx), h, w, amax, hip.ptr(out[0]), hip.ptr(out[1]),
+                                              hip.stream_ptr()))
+            peak, first = out.cpu().numpy()
+            tables = {dye: self._table(panel, dye) for dye in range(h) if dye in panel.dye_bp_to_allele_mapping}
+            for k, i in enumerate(idx):
+                dyes, js = np.nonzero(first[k] != ABSENT)
+                order = np.lexsort((first[k][dyes, js], dyes))       # dye rows in order, runs left to right
+                loci: Dict[Tuple[int, str], Dict[str, None]] = {}
+                rfus: Dict[Tuple[str, str], int] = {}
+                for d, j in zip(dyes[order].tolist(), js[order].tolist()):
+                    marker_name, allele_name = tables[d].names[j]
+                    loci.setdefault((d, marker_name), {})[allele_name] = None
+                    key = (marker_name, allele_name)
+                    rfus[key] = max(rfus.get(key, 0), int(peak[k, d, j]))
+                called = [Marker(dye, marker_name, alleles=[Allele(name=a, height=rfus[(marker_name, a)]) for a in alleles])
+                          for (dye, marker_name), alleles in loci.items()]
+                if "called_alleles_manual" in images[i].meta:
+                    called = [m for m in called if m.name not in NON_AUTOSOMAL_MARKERS]
+                predictions[i].meta["called_alleles"] = called
+        return predictions
+
+
+ABSENT = 0x7F7F7F7F      # DN_ALLELE_ABSENT (include/dnanet_hip.h)

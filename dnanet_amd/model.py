@@ -300,7 +300,11 @@ class DNANet_UNet(TrainableModel):
                        for i, image in enumerate(batch)]
         if self.allele_caller:
             LOGGER.info("Calling alleles from predicted segmentation...")
-            predictions = [self.allele_caller.call_alleles(im, pred) for im, pred in zip(batch, predictions)]
+            if hasattr(self.allele_caller, "call_alleles_batch"):
+                # device path: runs / nearest base pair / peak heights from the probability maps still in HBM
+                predictions = self.allele_caller.call_alleles_batch(batch, predictions, probs, inputs)
+            else:
+                predictions = [self.allele_caller.call_alleles(im, pred) for im, pred in zip(batch, predictions)]
         return predictions
 
     def predict_raw(self, images: Sequence) -> torch.Tensor:

@@ -139,6 +139,18 @@ int dn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
 /* int16 RFU -> fp32 (get_input, trainable_unet.py:70-72). */
 int dn_i16_to_f32(const short* in, float* out, long n, void* stream);
 
+/* ---- allele hand-off -------------------------------------------------------------------------
+ * NearestBasePairCaller.translate_pixels_to_alleles (DNAnet/allele_callers.py:63-125) for a batch: probs and rfu are
+ * (N,H,W) fp32 (probabilities, raw RFU); scaler holds the base pair of every scan column (W doubles; one row per
+ * profile, scaler_stride apart, or shared when the stride is 0).  The panel is given per dye row h as the slice
+ * [table_off[h], table_off[h+1]) of table_bp (base pairs, ascending) and table_order (position in the panel, the
+ * tie-break).  Per profile, dye and table entry j < amax: out_rfu = highest RFU of the runs called as j (>= 0),
+ * out_first = first scan column that called j, or DN_ALLELE_ABSENT. */
+#define DN_ALLELE_ABSENT 0x7f7f7f7f
+int dn_call_alleles(const float* probs, const float* rfu, const double* scaler, long scaler_stride, const double* table_bp,
+                    const int* table_order, const int* table_off, int N, int H, int W, int amax, int* out_rfu, int* out_first,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif
