@@ -30,6 +30,15 @@ static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype
   // measured (N=256, W=4096 net): the 8-wave kernels win for 5-row tiles and for fp32; bf16 3-row tiles (6 dyes) are
   // faster on the 4-wave kernel at every level
   v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && v.ht == 5));
+  // Small batches (train.py's 16 profiles): the wide tiles leave CUs idle -- every 8-wave launch of the shipped net
+  // is exactly 128 workgroups at N = 16.  Step down to the tile that still gives two workgroups per CU.
+  if (p.N > 0) {
+    const long rows = (long)p.N * ((p.H + v.ht - 1) / v.ht);
+    const long blocks8 = rows * (p.W / 256) * (p.cout_pad / 64);
+    const long blocks64 = rows * ((p.W + 127) / 128) * (p.cout_pad / 64);
+    if (v.wave8 && blocks8 < 512) v.wave8 = false;
+    if (!v.wave8 && v.cot == 64 && blocks64 < 512) v.cot = 32;
+  }
   return v;
 }
 
@@ -63,11 +72,11 @@ extern "C" {
 const char* dn_last_error(void) { return g_err; }
 int dn_abi_version(void) { return 1; }
 
-int dn_conv2d_variant(int cin, int cout, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len) {
+int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len) {
   DN_CHECK_ARG(buf && buf_len > 0, "dn_conv2d_variant: no buffer");
   DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d_variant: bad dtype %d", dtype);
   ConvParams p{};
-  p.H = H; p.W = W; p.nchunk = dn_planes(cin, dtype); p.cout_pad = dn_channel_pad(cout); p.x_wmul = 1; p.y_wmul = 1;
+  p.N = N; p.H = H; p.W = W; p.nchunk = dn_planes(cin, dtype); p.cout_pad = dn_channel_pad(cout); p.x_wmul = 1; p.y_wmul = 1;
   const ConvVariant v = choose_variant(p, kh, kw, dtype);
   snprintf(buf, buf_len, "%s<%s,%dx%d,ht%d,cot%d>", v.wave8 ? (v.ht == 3 ? "conv_igemm8c" : "conv_igemm8") : "conv_igemm",
            dtype == DN_BF16 ? "bf16" : "f32", kh, kw, v.ht, v.cot);

@@ -18,6 +18,7 @@
 // Split-K partials go to a slab [slab][tap][co_pad][ci_pad] that a second kernel sums in fixed order
 // (bitwise reproducible; no float atomics) and scatters into the canonical parameter layout.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 
 struct WgradParams {
@@ -319,7 +320,9 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   p.ci_pad = (p.ci_pad + TR::CI_T - 1) / TR::CI_T * TR::CI_T;
   const long tiles = (long)(p.co_pad / TR::CO_T) * (p.ci_pad / TR::CI_T);
   const long per_slab = (long)TAPS * p.co_pad * p.ci_pad * 4 * (KSPLIT ? 4 : 1);
-  long nsplit = std::max<long>(1, (1024 + tiles - 1) / tiles);
+  static const char* tune_blocks = getenv("DN_TUNE_WGRAD_BLOCKS");   // tuning aid: split-K target grid size
+  const long target = tune_blocks ? atol(tune_blocks) : 512;   // two resident workgroups per CU
+  long nsplit = std::max<long>(1, (target + tiles - 1) / tiles);
   // >= 2048 pixels per block: every slab costs a round trip through HBM
   nsplit = std::min<long>(nsplit, std::max<long>(1, (long)p.nstrips * HT * SW / 2048));
   nsplit = std::min<long>(nsplit, slab_bytes / per_slab);

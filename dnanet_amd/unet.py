@@ -142,11 +142,11 @@ class HipUNet(ParameterTree):
         self._eval_cache = cache
         self._eval_cache_version = self._versions()
 
-    def conv_kernel_tag(self, cin: int, cout: int, h: int, w: int) -> str:
+    def conv_kernel_tag(self, cin: int, cout: int, n: int, h: int, w: int) -> str:
         """Name of the instantiation the library dispatches this convolution to (api.hip: choose_variant)."""
         kh, kw = self.kernel_size
         buf = ctypes.create_string_buffer(96)
-        hip.check(hip.lib.dn_conv2d_variant(cin, cout, h, w, kh, kw, self.dtype, buf, len(buf)))
+        hip.check(hip.lib.dn_conv2d_variant(cin, cout, n, h, w, kh, kw, self.dtype, buf, len(buf)))
         return buf.value.decode()
 
     def _conv(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1):
@@ -156,7 +156,7 @@ class HipUNet(ParameterTree):
             self._conv_launch(u, entry, src, dst, n, h, w, relu)
             e1.record()
             kh, kw = self.kernel_size
-            self.profile.append((self.conv_kernel_tag(u.cin, u.cout, h, w), 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
+            self.profile.append((self.conv_kernel_tag(u.cin, u.cout, n, h, w), 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
         else:
             self._conv_launch(u, entry, src, dst, n, h, w, relu)
 

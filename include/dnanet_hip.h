@@ -53,10 +53,10 @@ long dn_packed_weight_bytes(int cout, int cin, int kh, int kw, int mode, int dty
 int dn_pack_weight(const float* w, const float* scale, void* packed, int cout, int cin, int kh, int kw, int mode,
                    int dtype, void* stream);
 
-/* Name of the kernel instantiation dn_conv2d dispatches a (cin -> cout, H x W, kh x kw) convolution to, e.g.
+/* Name of the kernel instantiation dn_conv2d dispatches a (cin -> cout, N x H x W, kh x kw) convolution to, e.g.
  * "conv_igemm8<bf16,3x5,ht5,cot64>".  No counterpart in the reference (torch picks its cuDNN / MIOpen algorithm
  * internally, unet_architecture.py:14-16 only names nn.Conv2d); bench.py groups its per-launch timings by it. */
-int dn_conv2d_variant(int cin, int cout, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len);
+int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len);
 
 /* ---- forward operators -------------------------------------------------------------------- */
 /* nn.Conv2d(1, cout, (kh,kw), padding=k//2) on the raw fp32 input x[N][1][H][W]
