@@ -67,20 +67,20 @@ __device__ __forceinline__ double wave_sum_partials(const float* partial, int nb
 // RED_SEG pieces and the (image, segment) units are dealt round-robin to the blocks of a plane.  A thread reads four
 // pieces 256 apart per step (independent loads in flight: a single dependent load per thread left HBM at ~4 TB/s);
 // its piece parity, hence its channels, is fixed (threadIdx.x & 1).
-constexpr int RED_SEG = 4096;
+constexpr int RED_SEG = 4096;      // pieces per unit at large batch; red_seg() shrinks it when there are few images
 
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned char* y, int planes_total, int plane0, int N,
-                                                                int npieces, float* partial, int cpad) {
+                                                                int npieces, int seg_len, float* partial, int cpad) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
   const int plane = blockIdx.y;
   float acc[2][PN] = {};
-  const int nseg = (npieces + RED_SEG - 1) / RED_SEG;
+  const int nseg = (npieces + seg_len - 1) / seg_len;
   for (int u = blockIdx.x; u < N * nseg; u += gridDim.x) {
     const int n = u / nseg, seg = u - n * nseg;
     const unsigned char* base = y + ((long)n * planes_total + plane0 + plane) * npieces * 16;
-    const int iend = min(npieces, (seg + 1) * RED_SEG);
-    for (int i = seg * RED_SEG + threadIdx.x; i < iend; i += 4 * RED_THREADS) {
+    const int iend = min(npieces, (seg + 1) * seg_len);
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += 4 * RED_THREADS) {
       uint4 v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -156,7 +156,7 @@ template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsigned char* g, int g_pt, int g_p0,
                                                                      const unsigned char* y, int y_pt, int y_p0,
                                                                      const float* __restrict__ scale,
-                                                                     const float* __restrict__ shift, int N, int npieces,
+                                                                     const float* __restrict__ shift, int N, int npieces, int seg_len,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ invstd, float* partial, int cpad) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
@@ -166,13 +166,13 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsign
 #pragma unroll
   for (int j = 0; j < PN; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
   float acc[2][PN] = {};
-  const int nseg = (npieces + RED_SEG - 1) / RED_SEG;
+  const int nseg = (npieces + seg_len - 1) / seg_len;
   for (int u = blockIdx.x; u < N * nseg; u += gridDim.x) {
     const int n = u / nseg, seg = u - n * nseg;
     const unsigned char* gbase = g + ((long)n * g_pt + g_p0 + plane) * npieces * 16;
     const unsigned char* ybase = y + ((long)n * y_pt + y_p0 + plane) * npieces * 16;
-    const int iend = min(npieces, (seg + 1) * RED_SEG);
-    for (int i = seg * RED_SEG + threadIdx.x; i < iend; i += 2 * RED_THREADS) {
+    const int iend = min(npieces, (seg + 1) * seg_len);
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += 2 * RED_THREADS) {
       uint4 vg[2], vy[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -470,6 +470,12 @@ __global__ void sum_finalize_kernel(const float* partial, int nblk, float* out) 
 }
 
 inline unsigned ew_grid(long total) { return (unsigned)std::min<long>((total + 255) / 256, 8192); }
+// segment length of the plane reductions: RED_SEG pieces, halved while the launch would leave CUs without work
+inline int red_seg(int N, int nplanes, int npieces) {
+  int seg = RED_SEG;
+  while (seg > 1024 && (long)N * nplanes * ((npieces + seg - 1) / seg) < 2048) seg >>= 1;
+  return seg;
+}
 inline int red_blocks(long pixels) { return (int)std::max<long>(1, std::min<long>((pixels + 127) / 128, RED_MAX_BLOCKS)); }
 
 }  // namespace
@@ -494,8 +500,8 @@ int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const flo
   const int nblk = red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
   DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(bn_stats_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), partial, cpad),
-    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), partial, cpad),
+    hipLaunchKernelGGL(bn_stats_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), partial, cpad),
+    hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), partial, cpad),
     "dn_bn_train_forward");
   DN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
@@ -523,7 +529,7 @@ int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const flo
   const int nblk = red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
 #define ARGS_R (const unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)y.base, y.planes_total, y.plane0, \
-               scale, shift, N, (int)(HW * 2), mean, invstd, partial, cpad
+               scale, shift, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), mean, invstd, partial, cpad
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
