@@ -37,6 +37,10 @@ template <> struct WgTraits<float>  { static constexpr int CO_T = 32, CI_T = 32,
 // strip = HT dye rows x SW scan columns of one image.  Row tiles (HT > 1) exist for the 3-row kernels: the KH-1 halo
 // rows of A are then fetched once per HT output rows instead of once per row, which is what moves the kernel from
 // the L2 bandwidth bound to the MFMA bound (bytes staged per flop: x0.6 at HT = 5).
+// input-channel tile: a single-tap (1x1 / transposed-convolution) gradient has one accumulator set per wave, so it can
+// afford 128 input channels per tile -- dY is then re-read 4x less often (it is a plain [co x pixels] x [pixels x ci]
+// GEMM that is bound by how often the operands are re-streamed from L2)
+constexpr int wg_ci_tile(int taps, int elem_bytes) { return taps == 1 ? (elem_bytes == 2 ? 128 : 64) : 32; }   // fp32: LDS budget
 template <typename T> constexpr int wg_strip_width(int ht) { return ht == 1 ? 64 : (sizeof(T) == 2 ? 32 : 16); }
 
 __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   using TR = WgTraits<T>;
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
   constexpr int EPR = RecTraits<T>::EPR;
-  constexpr int CO_T = TR::CO_T, CI_T = TR::CI_T, KSTEP = TR::KSTEP;
+  constexpr int CO_T = TR::CO_T, CI_T = wg_ci_tile(TAPS, sizeof(T)), KSTEP = TR::KSTEP;
   constexpr int NCOG = CO_T / 32, NCIG = CI_T / 32;
   constexpr int CO_PL = CO_T / EPR, CI_PL = CI_T / EPR;     // planes per tile
   constexpr int PLG = 32 / EPR;                             // planes per 32-channel group
@@ -317,8 +321,9 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
     return dn_set_error(DN_ERR_ARG, "conv_wgrad: one image of an operand exceeds 2 GiB (32-bit buffer offsets)");
   p.nstrips = p.N * p.nth * p.ntw;
   p.co_pad = (p.co_pad + TR::CO_T - 1) / TR::CO_T * TR::CO_T;
-  p.ci_pad = (p.ci_pad + TR::CI_T - 1) / TR::CI_T * TR::CI_T;
-  const long tiles = (long)(p.co_pad / TR::CO_T) * (p.ci_pad / TR::CI_T);
+  constexpr int CI_T = wg_ci_tile(TAPS, sizeof(T));
+  p.ci_pad = (p.ci_pad + CI_T - 1) / CI_T * CI_T;
+  const long tiles = (long)(p.co_pad / TR::CO_T) * (p.ci_pad / CI_T);
   const long per_slab = (long)TAPS * p.co_pad * p.ci_pad * 4 * (KSPLIT ? 4 : 1);
   static const char* tune_blocks = getenv("DN_TUNE_WGRAD_BLOCKS");   // tuning aid: split-K target grid size
   const long target = tune_blocks ? atol(tune_blocks) : 512;   // two resident workgroups per CU

@@ -105,7 +105,7 @@ int dn_conv2d_wgrad(dn_tensor dy, dn_tensor a, float* dw, void* workspace, long 
   p.dy_gplanes = 1 << 30; p.dy_wmul = 1;
   p.a = a.base; p.a_pt = a.planes_total; p.a_p0 = a.plane0; p.a_nplanes = dn_planes(a.channels, dtype);
   p.slab = (float*)workspace; p.N = N; p.H = H; p.W = W;
-  p.co_pad = tile_pad(dy.channels, co_t); p.ci_pad = tile_pad(p.a_nplanes * epr, 32);
+  p.co_pad = tile_pad(dy.channels, co_t); p.ci_pad = tile_pad(p.a_nplanes * epr, wg_ci_tile(kh * kw, dtype == DN_BF16 ? 2 : 4));
   DN_CHECK_ARG(dy.plane0 + p.dy_nplanes <= dy.planes_total && a.plane0 + p.a_nplanes <= a.planes_total,
                "dn_conv2d_wgrad: planes outside buffer");
   int nslab = 0;
@@ -138,7 +138,7 @@ int dn_conv_transpose_1x2_wgrad(dn_tensor dy, dn_tensor x, float* dw, void* work
   p.dy_gplanes = gsize / epr; p.dy_wmul = 2;
   p.a = x.base; p.a_pt = x.planes_total; p.a_p0 = x.plane0; p.a_nplanes = dn_planes(x.channels, dtype);
   p.slab = (float*)workspace; p.N = N; p.H = H; p.W = Win;
-  p.co_pad = 2 * gsize; p.ci_pad = tile_pad(p.a_nplanes * epr, 32);
+  p.co_pad = 2 * gsize; p.ci_pad = tile_pad(p.a_nplanes * epr, wg_ci_tile(1, dtype == DN_BF16 ? 2 : 4));
   int nslab = 0;
   int rc = run_wgrad(p, workspace_bytes, 1, 1, dtype, &nslab, (hipStream_t)stream);
   if (rc) return rc;
