@@ -26,6 +26,10 @@ static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype
   // narrow (32-channel) tiles have room for 6 accumulator rows: one 6-row tile instead of two 3-row ones halves the
   // per-block fixed cost that dominates the 2-4 chunk layers
   if (kh == 3 && kw == 5 && v.cot == 32 && v.ht == 3 && p.H % 6 == 0) v.ht = 6;
+  // a 1x1 GEMM (transposed convolution) is bound by how often the activation tile is re-streamed from L2: 128 output
+  // channels x 2 rows halves that against 64 x 5 (rows are 128-pixel slices of the flattened plane, so H is even)
+  static const char* no128 = getenv("DN_TUNE_NO_COT128");
+  if (!no128 && kh == 1 && kw == 1 && p.cout_pad % 128 == 0 && p.H % 2 == 0) { v.ht = 2; v.cot = 128; return v; }
   static const char* no8 = getenv("DN_TUNE_NO_CONV8");        // tuning aid: keep the 4-wave kernel everywhere
   // measured (N=256, W=4096 net): the 8-wave kernels win for 5-row tiles and for fp32; bf16 3-row tiles (6 dyes) are
   // faster on the 4-wave kernel at every level
