@@ -339,51 +339,44 @@ __global__ void channel_sum_finalize_kernel(const float* partial, int nblk, int 
 }
 
 // ---- first-convolution weight gradient: dW[co][tap] = sum_pix dy[pix][co] * x[pix + tap] ------------
-// block = 16 pixel lanes x 16 tap slots; grid (chunks, planes); partial[chunk][tap][cpad]
+// A thread owns one 16-byte piece (8 bf16 / 4 fp32 channels) of one pixel per step and all TAPS accumulators for it:
+// dy is read exactly once (16 B per lane, coalesced), the KH*KW neighbours of x come from L1 (fp32: raw RFU does not
+// fit bf16), 8*TAPS FMAs per load.  Per-block partial[blk][c][tap] via the common wave/LDS reduction.
 template <typename T, int KH, int KW>
-__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ x, const unsigned char* dy, int dy_pt,
-                                                               int dy_p0, long N, int H, int W, float* partial, int cpad) {
+__global__ __launch_bounds__(RED_THREADS) void conv_first_wgrad_kernel(const float* __restrict__ x, const unsigned char* dy,
+                                                                        int dy_pt, int dy_p0, int N, int H, int W,
+                                                                        float* partial, int cpad) {
   constexpr int EPR = RecTraits<T>::EPR, PN = Piece<T>::N, TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
-  static_assert(TAPS <= 16, "tap slots");
-  __shared__ float red[16][16][EPR + 1];
-  const int plane = blockIdx.y;
-  const int tap = threadIdx.x & 15, pl = threadIdx.x >> 4;
-  const int dh = tap / KW - PH, dw = tap % KW - PW;
-  float acc[EPR] = {};
-  const long HW = (long)H * W, total = N * HW;
-  if (tap < TAPS) {
-    for (long i = (long)blockIdx.x * 16 + pl; i < total; i += (long)gridDim.x * 16) {
-      const long n = i / HW;
-      const long hw = i - n * HW;
-      const int h = (int)(hw / W), w = (int)(hw - (long)h * W);
-      const int hh = h + dh, ww = w + dw;
-      if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-      const float xv = x[(n * H + hh) * W + ww];
-      const unsigned char* src = dy + rec_off(dy_pt, dy_p0 + plane, n, hw, HW);
-      float f[EPR];
-      Piece<T>::unpack(*(const uint4*)src, f);
-      Piece<T>::unpack(*(const uint4*)(src + 16), f + PN);
+  const int plane = blockIdx.y, pc = threadIdx.x & 1;
+  float acc[TAPS][PN] = {};
+  const unsigned HW = (unsigned)H * W, total = (unsigned)N * HW;
+  for (unsigned i = blockIdx.x * 128u + (threadIdx.x >> 1); i < total; i += gridDim.x * 128u) {
+    const unsigned n = i / HW, hw = i - n * HW;
+    const int h = (int)(hw / (unsigned)W), w = (int)(hw - (unsigned)h * W);
+    float f[PN];
+    Piece<T>::unpack(*(const uint4*)(dy + rec_off(dy_pt, dy_p0 + plane, n, hw, HW) + 16 * pc), f);
+    const float* xrow = x + (long)n * HW;
 #pragma unroll
-      for (int c = 0; c < EPR; ++c) acc[c] = fmaf(xv, f[c], acc[c]);
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hh = h + kh - PH;
+      const bool row_ok = hh >= 0 && hh < H;
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        const int ww = w + kw - PW;
+        const float xv = (row_ok && ww >= 0 && ww < W) ? xrow[hh * W + ww] : 0.f;
+#pragma unroll
+        for (int j = 0; j < PN; ++j) acc[kh * KW + kw][j] = fmaf(xv, f[j], acc[kh * KW + kw][j]);
+      }
     }
   }
-#pragma unroll
-  for (int c = 0; c < EPR; ++c) red[pl][tap][c] = acc[c];
-  __syncthreads();
-  for (int o = threadIdx.x; o < TAPS * EPR; o += blockDim.x) {
-    const int t = o / EPR, c = o % EPR;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s += red[k][t][c];
-    partial[((long)blockIdx.x * TAPS + t) * cpad + plane * EPR + c] = s;
-  }
+  block_reduce_store<TAPS, PN>(acc, partial, cpad, plane, EPR);
 }
 
 __global__ void conv_first_wgrad_finalize_kernel(const float* partial, int nblk, int taps, int cpad, int C, float* dw /*[C][taps]*/) {
   const int i = blockIdx.x;       // one wave per (channel, tap)
   if (i >= C * taps) return;
   const int c = i / taps, t = i % taps;
-  const double s = wave_sum_partials(partial, nblk, (long)taps * cpad, (long)t * cpad + c);
+  const double s = wave_sum_partials(partial, nblk, (long)taps * cpad, (long)c * taps + t);
   if (threadIdx.x == 0) dw[i] = (float)s;
 }
 
@@ -622,10 +615,11 @@ int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial,
                         void* stream) {
   DN_CHECK_ARG(x && dy.base && dw && partial, "dn_conv_first_wgrad: null pointer");
   const int C = dy.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype), taps = kh * kw;
-  const int nblk = (int)std::max<long>(1, std::min<long>(((long)N * H * W + 15) / 16, 256));
+  const int nblk = dn_conv_first_wgrad_blocks(N, H, W);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(TT, KH, KW) hipLaunchKernelGGL((conv_first_wgrad_kernel<TT, KH, KW>), dim3(nblk, nplanes), dim3(256), 0, s, x, \
-    (const unsigned char*)dy.base, dy.planes_total, dy.plane0, (long)N, H, W, partial, cpad)
+  DN_CHECK_ARG((long)N * H * W < (1L << 31), "dn_conv_first_wgrad: more than 2^31 pixels");
+#define LAUNCH(TT, KH, KW) hipLaunchKernelGGL((conv_first_wgrad_kernel<TT, KH, KW>), dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, x, \
+    (const unsigned char*)dy.base, dy.planes_total, dy.plane0, N, H, W, partial, cpad)
   if (kh == 3 && kw == 5) { DN_DISPATCH_T(dtype, LAUNCH(__bf16, 3, 5), LAUNCH(float, 3, 5), "dn_conv_first_wgrad"); }
   else if (kh == 1 && kw == 3) { DN_DISPATCH_T(dtype, LAUNCH(__bf16, 1, 3), LAUNCH(float, 1, 3), "dn_conv_first_wgrad"); }
   else if (kh == 1 && kw == 1) { DN_DISPATCH_T(dtype, LAUNCH(__bf16, 1, 1), LAUNCH(float, 1, 1), "dn_conv_first_wgrad"); }
@@ -638,7 +632,7 @@ int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial,
 }
 
 int dn_conv_first_wgrad_blocks(int N, int H, int W) {
-  return (int)std::max<long>(1, std::min<long>(((long)N * H * W + 15) / 16, 256));
+  return (int)std::max<long>(1, std::min<long>(((long)N * H * W + 127) / 128, 512));
 }
 
 int dn_dice_forward(const float* logits, const signed char* targets, long n, float* sums, float* partial, void* stream) {
