@@ -149,6 +149,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
     return s;
   };
   auto issue_act = [&](const dn_srd_t& srd, int abuf, int step) {     // APW pieces of one activation image
+#ifdef C8_ABLATE_NO_STAGE   // (ablation hook: scratch/conv8_micro.hip)
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < APW; ++k) {
       const int i = step * APW + k;
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
     }
   };
   auto issue_w = [&](const dn_srd_t& srd, int dwi) {                  // one piece of one weight slice
+#ifdef C8_ABLATE_NO_STAGE
+    return;
+#endif
     dn_buffer_lds16(w_off, srd, __builtin_amdgcn_readfirstlane(smem_lds + (wave < 6 ? W_OFF + dwi * W_SLICE + wave * 1024 : SCRAP_OFF)));
   };
 
