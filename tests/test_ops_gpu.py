@@ -56,7 +56,55 @@ CONV_CASES = [
     (2, 8, 16, 5, 130, 1, 3),
     (1, 48, 64, 6, 64, 1, 3),
     (2, 32, 32, 5, 64, 1, 1),
+    (2, 32, 32, 6, 256, 3, 5),         # narrow tile, one 6-row tile (conv_igemm<..,ht6,cot32>)
+    (2, 128, 128, 4, 128, 1, 1),       # 1x1 GEMM with 2-row x 128-channel tiles
 ]
+
+# large enough grids to be dispatched to the 8-wave pipelined kernels (api.hip choose_variant): name -> expected variant
+CONV8_CASES = [
+    ((128, 64, 64, 5, 1024, 3, 5), {0: "conv_igemm8<f32,3x5,ht5,cot64>", 1: "conv_igemm8<bf16,3x5,ht5,cot64>"}),
+    ((64, 64, 64, 6, 1024, 3, 5), {0: "conv_igemm8c<f32,3x5,ht3,cot64>", 1: "conv_igemm<bf16,3x5,ht3,cot64>"}),
+    ((130, 80, 128, 5, 512, 3, 5), {0: "conv_igemm8<f32,3x5,ht5,cot64>", 1: "conv_igemm8<bf16,3x5,ht5,cot64>"}),
+]
+
+
+def _variant(hip, cin, cout, n, h, w, kh, kw, dtype):
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    hip.check(hip.lib.dn_conv2d_variant(cin, cout, n, h, w, kh, kw, dtype, buf, len(buf)))
+    return buf.value.decode()
+
+
+def test_variant_names(gpu_device):
+    hip = _hip()
+    assert _variant(hip, 32, 32, 2, 6, 256, 3, 5, 1) == "conv_igemm<bf16,3x5,ht6,cot32>"
+    assert _variant(hip, 128, 128, 2, 4, 128, 1, 1, 1) == "conv_igemm<bf16,1x1,ht2,cot128>"
+    assert _variant(hip, 512, 512, 256, 5, 256, 3, 5, 1) == "conv_igemm8<bf16,3x5,ht5,cot64>"
+    assert _variant(hip, 512, 512, 16, 5, 256, 3, 5, 1) == "conv_igemm<bf16,3x5,ht5,cot32>"     # small batch: narrow tiles
+    assert _variant(hip, 512, 512, 256, 6, 256, 3, 5, 1) == "conv_igemm<bf16,3x5,ht3,cot64>"
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case,expect", CONV8_CASES)
+def test_conv2d_8wave(gpu_device, case, expect, dtype):
+    """Integer data: exact in both dtypes, so every tap, halo row, image border and pipeline stage must be right."""
+    hip = _hip()
+    n, cin, cout, h, w, kh, kw = case
+    assert _variant(hip, cin, cout, n, h, w, kh, kw, dtype) == expect[dtype]
+    g = torch.Generator().manual_seed(7 + dtype)
+    x = torch.randint(-2, 3, (n, cin, h, w), generator=g).float()
+    wt = torch.randint(-1, 2, (cout, cin, kh, kw), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    ref = F.conv2d(x, wt, b, padding=(kh // 2, kw // 2)).relu()
+    xb = hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype)
+    packed = _pack(hip, wt, None, hip.PACK_FWD, dtype, gpu_device)
+    bias = _padvec(b, hip.channel_pad(cout), gpu_device)
+    yb = hip.PlaneBuffer(n, hip.planes(cout, dtype) + 2, h, w, dtype, gpu_device, zero=True)
+    hip.check(hip.lib.dn_conv2d(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), yb.ref(cout, 1), n, h, w, kh, kw, 1, dtype,
+                                hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(yb.to_nchw(cout, 1).cpu(), _q(ref, dtype))
+    assert float(yb.data[:, :1].abs().max()) == 0 and float(yb.data[:, -1:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
