@@ -61,12 +61,14 @@ def run(data_config, model_config, training_config, evaluation_config, nr_folds,
     if gpus > 1:
         # one process per fold, fold i on GPU (i-1) mod gpus, at most `gpus` at a time; the split is deterministic
         # (seed 42), so every worker derives the same folds
+        import torch
+        n_devices = max(1, torch.cuda.device_count())     # counting devices does not initialise the GPU in this process
         pending = list(range(1, nr_folds + 1))
         while pending:
             batch, pending = pending[:gpus], pending[gpus:]
             procs = []
             for slot, i in enumerate(batch):
-                env = dict(os.environ, HIP_VISIBLE_DEVICES=str(slot), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                env = dict(os.environ, HIP_VISIBLE_DEVICES=str(slot % n_devices), HSA_ENABLE_IPC_MODE_LEGACY="0")
                 cmd = [sys.executable, os.path.abspath(__file__), "-d", data_config, "-m", model_config, "-t", training_config,
                        "-e", evaluation_config, "-k", str(nr_folds), "-o", output_dir, "--only-fold", str(i)]
                 if validation_config:

@@ -105,3 +105,11 @@ def test_train_evaluate_cross_validate_end_to_end(tmp_path, monkeypatch, gpu_dev
                              os.path.join(ROOT, "config/evaluation/segmentation.yaml"), 3, output_dir=str(cv))
     assert all((cv / f"fold_{i}" / "metrics.txt").is_file() for i in (1, 2, 3)) and (cv / "agg_metrics.txt").is_file()
     assert all(np.isfinite(v) or np.isnan(v) for v in agg.values())
+    # folds as worker processes (one per GPU slot; on a one-GPU box both slots map to device 0): same split, same files
+    cv2 = tmp_path / "cv2"
+    cross_validate.run(str(cfg / "data.yaml"), str(cfg / "model.yaml"), str(cfg / "train.yaml"),
+                       os.path.join(ROOT, "config/evaluation/segmentation.yaml"), 3, output_dir=str(cv2), gpus=2)
+    assert all((cv2 / f"fold_{i}" / "metrics.txt").is_file() for i in (1, 2, 3)) and (cv2 / "agg_metrics.txt").is_file()
+    for i in (1, 2, 3):       # deterministic folds and seeded models: the worker run reproduces the in-process run
+        a = json.load(open(cv / f"fold_{i}" / "metrics.txt")); b = json.load(open(cv2 / f"fold_{i}" / "metrics.txt"))
+        assert a.keys() == b.keys()
