@@ -7,7 +7,10 @@
 #include "ops.h"
 
 // ------------------------------------------------------------------------------------------------
-// first convolution: x [N][H][W] fp32 -> y planes, one thread = one output record (EPR channels)
+// first convolution: x [N][H][W] fp32 -> y planes.  One thread = one 16-byte output piece (8 bf16 / 4 fp32 channels) of
+// one scan column, walking down the dye rows: its KH*KW x PN weights live in registers for the whole walk, the KH x KW
+// input window slides (KW new x values per output, coalesced across lanes), stores are 16 B per lane, contiguous.
+// Grid (column blocks, planes, images): no division anywhere.
 // wf: [taps][cpad] fp32 (already multiplied by the folded BN scale when inference), bias [cpad]
 // ------------------------------------------------------------------------------------------------
 template <typename T, int KH, int KW>
@@ -15,40 +18,50 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          const float* __restrict__ bias, unsigned char* y,
                                                          int y_planes_total, int y_plane0, int N, int H, int W,
                                                          int cpad, int relu) {
-  constexpr int EPR = RecTraits<T>::EPR, TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
-  __shared__ float ws[TAPS * EPR + EPR];
-  const int plane = blockIdx.y;
-  for (int i = threadIdx.x; i < TAPS * EPR; i += blockDim.x) ws[i] = wf[(i / EPR) * cpad + plane * EPR + (i % EPR)];
-  if (threadIdx.x < EPR) ws[TAPS * EPR + threadIdx.x] = bias ? bias[plane * EPR + threadIdx.x] : 0.f;
-  __syncthreads();
-  const long total = (long)N * H * W;
-  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
-    const int w = (int)(pix % W);
-    const int h = (int)((pix / W) % H);
-    const long n = pix / ((long)W * H);
-    float acc[EPR];
+  constexpr int EPR = RecTraits<T>::EPR, PN = Piece<T>::N, TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
+  const int plane = blockIdx.y, n = blockIdx.z;
+  const int pc = threadIdx.x & 1, w = blockIdx.x * 128 + (threadIdx.x >> 1);
+  if (w >= W) return;
+  const int c0 = plane * EPR + pc * PN;
+  float wt[TAPS][PN], b[PN];
 #pragma unroll
-    for (int c = 0; c < EPR; ++c) acc[c] = ws[TAPS * EPR + c];
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int dh = 0; dh < KH; ++dh) {
-      const int hh = h + dh - PH;
-      if (hh < 0 || hh >= H) continue;
+    for (int j = 0; j < PN; ++j) wt[t][j] = wf[t * cpad + c0 + j];
 #pragma unroll
-      for (int dw = 0; dw < KW; ++dw) {
-        const int ww = w + dw - PW;
-        if (ww < 0 || ww >= W) continue;
-        const float xv = x[(n * H + hh) * W + ww];
+  for (int j = 0; j < PN; ++j) b[j] = bias ? bias[c0 + j] : 0.f;
+  const float* xn = x + (long)n * H * W;
+  auto load_row = [&](int hh, float (&row)[KW]) {
 #pragma unroll
-        for (int c = 0; c < EPR; ++c) acc[c] = fmaf(xv, ws[(dh * KW + dw) * EPR + c], acc[c]);
-      }
+    for (int k = 0; k < KW; ++k) {
+      const int ww = w + k - PW;
+      row[k] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xn[hh * W + ww] : 0.f;
     }
+  };
+  float win[KH][KW];                       // rows h-PH .. h+PH of the window
+#pragma unroll
+  for (int r = 0; r < KH - 1; ++r) load_row(r - PH, win[r + 1]);      // pre-load so that the first shift lines up
+  unsigned char* dst = y + ((((long)n * y_planes_total + y_plane0 + plane) * H) * (long)W + w) * 32 + 16 * pc;
+  for (int h = 0; h < H; ++h, dst += (long)W * 32) {
+#pragma unroll
+    for (int r = 0; r < KH - 1; ++r)
+#pragma unroll
+      for (int k = 0; k < KW; ++k) win[r][k] = win[r + 1][k];
+    load_row(h + KH - 1 - PH, win[KH - 1]);
+    float acc[PN];
+#pragma unroll
+    for (int j = 0; j < PN; ++j) acc[j] = b[j];
+#pragma unroll
+    for (int r = 0; r < KH; ++r)
+#pragma unroll
+      for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int j = 0; j < PN; ++j) acc[j] = fmaf(win[r][k], wt[r * KW + k][j], acc[j]);
     if (relu) {
 #pragma unroll
-      for (int c = 0; c < EPR; ++c) acc[c] = fmaxf(acc[c], 0.f);
+      for (int j = 0; j < PN; ++j) acc[j] = fmaxf(acc[j], 0.f);
     }
-    unsigned char* dst = y + (((n * y_planes_total + y_plane0 + plane) * H + h) * (long)W + w) * 32;
     *(uint4*)dst = Piece<T>::pack(acc);
-    *(uint4*)(dst + 16) = Piece<T>::pack(acc + Piece<T>::N);
   }
 }
 
@@ -58,8 +71,8 @@ static int conv_first_t(const float* x, const float* wf, const float* bias, dn_t
   constexpr int EPR = RecTraits<T>::EPR;
   const int nplanes = (cout + EPR - 1) / EPR;
   const int cpad = dn_channel_pad(cout);
-  const long total = (long)N * H * W;
-  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 4096), nplanes);
+  if (N >= 65536 || nplanes >= 65536) return dn_set_error(DN_ERR_ARG, "conv_first: batch or channels too large for the grid");
+  dim3 grid((unsigned)((W + 127) / 128), nplanes, N);
 #define LAUNCH(KH, KW) hipLaunchKernelGGL((conv_first_kernel<T, KH, KW>), grid, dim3(256), 0, s, x, wf, bias, \
     (unsigned char*)y.base, y.planes_total, y.plane0, N, H, W, cpad, relu)
   if (kh == 3 && kw == 5) LAUNCH(3, 5);
