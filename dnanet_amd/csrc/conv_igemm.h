@@ -29,6 +29,9 @@ struct ConvParams {
   int cout_pad;             // multiple of COT
   int relu;
   int ntw, nth;             // column / row tiles per image
+#ifdef C8_PROFILE_WAIT
+  long long* dbg;           // [waves][3]: cycles in vmcnt waits, in barriers, total (scratch/conv8_micro.hip)
+#endif
 };
 
 template <typename T> struct Mma32;

@@ -185,6 +185,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
+#ifdef C8_PROFILE_WAIT
+  long long prof_wait = 0, prof_bar = 0;
+  const long long prof_t0 = clock64(), prof_w0 = wall_clock64();
+#endif
   auto mainloop = [&](auto skip_top_c, auto skip_bot_c) {
     constexpr bool SKIP_TOP = decltype(skip_top_c)::value, SKIP_BOT = decltype(skip_bot_c)::value;
     // fragments of the NEXT step are read at the end of the current one (activation rows: all; weights: kernel row 0),
@@ -216,8 +220,19 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
         // weight slice of the NEXT step (issued three steps ago) must have landed -- and at step 4 the next chunk's
         // activations (issued in steps 0-1, older); everything issued after that may still be in flight:
         constexpr int NEWER = dwi == 0 ? 2 : dwi == 1 ? 2 + APW : dwi == 2 ? 2 + 2 * APW : dwi == 3 ? 2 + APW : 2;
+#ifdef C8_PROFILE_WAIT
+        const long long tw0 = clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+#ifdef C8_PROFILE_WAIT
+        const long long tw1 = clock64();
+#endif
+#ifndef C8_ABLATE_NO_BARRIER
         __syncthreads();   // everyone's pieces landed; everyone is done with the previous step's slice / act image
+#endif
+#ifdef C8_PROFILE_WAIT
+        prof_wait += tw1 - tw0; prof_bar += clock64() - tw1;
+#endif
         if (dwi < ACT_STEPS) issue_act(sa_next, (ck + 1) & 1, dwi);
         // refill the slice the previous step finished with: step 0 -> slice 4 of THIS chunk, step d -> slice d-1 of the next
         if (dwi == 0) issue_w(srd_wslice(ck, KW - 1), KW - 1);
@@ -262,6 +277,12 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   constexpr int NPL = COT / EPR;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef C8_PROFILE_WAIT
+  if (lane == 0 && p.dbg) {
+    long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 3;
+    d[0] = prof_wait; d[1] = (wall_clock64() - prof_w0) | ((long long)prof_bar << 24); d[2] = clock64() - prof_t0;
+  }
+#endif
   conv_epilogue_store<T, HT, COT>(p, acc, smem + wave * (NPL * 1024), n, h0, w0 + 32 * wave, cot, lane);
 }
 
