@@ -157,15 +157,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 
 #pragma unroll
   for (int i = 0; i < NBUF - 1; ++i) stage(i, i);
+#ifdef C8_PROFILE_WAIT
+  long long prof_wait = 0;
+  const long long prof_t0 = clock64(), prof_w0 = wall_clock64();
+#endif
   auto mainloop = [&](auto skip_top_c, auto skip_bot_c) {
   constexpr bool SKIP_TOP = decltype(skip_top_c)::value, SKIP_BOT = decltype(skip_bot_c)::value;
   int buf = 0;
   for (int ck = 0; ck < p.nchunk; ++ck, buf = buf + 1 == NBUF ? 0 : buf + 1) {
     if constexpr (NBUF == 1) {
+#ifdef C8_PROFILE_WAIT
+      const long long tp0 = clock64();
+#endif
       __syncthreads();   // previous chunk's fragment reads are done
       stage(ck, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#ifdef C8_PROFILE_WAIT
+      prof_wait += clock64() - tp0;
+#endif
     } else {
       // LDS-DMA completes in issue order: all but the newest NBUF-2 chunks in flight have landed
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ST_ITERS) : "memory");
@@ -222,6 +232,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   // every global store instruction writes 1 KiB of consecutive 16-byte pieces (32 pixels of one plane row)
   // instead of 8-byte fragments at a 32-byte stride.
   constexpr int NPL = COT / EPR;                    // output planes of this tile
+#ifdef C8_PROFILE_WAIT
+  if (lane == 0 && p.dbg) {
+    long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 3;
+    d[0] = prof_wait; d[1] = wall_clock64() - prof_w0; d[2] = clock64() - prof_t0;
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land on the scratch (or outlive the wave)
   __syncthreads();                                  // all waves are done reading the staged tiles
   unsigned char* scratch = smem_all + wave * (NPL * 1024);
