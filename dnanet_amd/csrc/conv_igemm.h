@@ -244,6 +244,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   unsigned char* yb = (unsigned char*)p.y;
   const int yrow = p.W * p.y_wmul;
   const int wbase = w0 + 32 * wave;
+  // this lane's 16 bias values per channel group, fetched once (one batch of loads, one wait) instead of inside the
+  // row loop, where every row paid a load latency
+  float bias_r[NCG][16];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      bias_r[cg][r] = p.bias ? p.bias[cot * COT + cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
 #pragma unroll
   for (int hh = 0; hh < HT; ++hh) {
     const int h = h0 + hh;
@@ -256,8 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            v[i] = acc[hh][cg][4 * g + i];
-            if (p.bias) v[i] += p.bias[cot * COT + cl + i];
+            v[i] = acc[hh][cg][4 * g + i] + bias_r[cg][4 * g + i];
             if (p.relu) v[i] = fmaxf(v[i], 0.f);
           }
           unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);

@@ -25,6 +25,14 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
   const int l31 = lane & 31, half = lane >> 5;
   unsigned char* yb = (unsigned char*)p.y;
   const int yrow = p.W * p.y_wmul;
+  // this lane's 16 bias values per channel group, fetched once (one batch of loads, one wait) instead of inside the
+  // row loop, where every row paid a load latency
+  float bias_r[NCG][16];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      bias_r[cg][r] = p.bias ? p.bias[cot * COT + cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
 #pragma unroll
   for (int hh = 0; hh < HT; ++hh) {
     const int h = h0 + hh;
@@ -37,8 +45,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            v[i] = acc[hh][cg][4 * g + i];
-            if (p.bias) v[i] += p.bias[cot * COT + cl + i];
+            v[i] = acc[hh][cg][4 * g + i] + bias_r[cg][4 * g + i];
             if (p.relu) v[i] = fmaxf(v[i], 0.f);
           }
           unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
@@ -91,6 +98,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
+#ifdef C8_PROFILE_WAIT
+  const long long prof_entry = clock64();
+#endif
 
   // block -> tile map: as conv_igemm.h (channel tiles fast inside an XCD)
   const int npt = p.N * p.nth * p.ntw;
@@ -282,8 +292,18 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
     long long* d = p.dbg + ((long)blockIdx.x * 8 + wave) * 3;
     d[0] = prof_wait; d[1] = (wall_clock64() - prof_w0) | ((long long)prof_bar << 24); d[2] = clock64() - prof_t0;
   }
+  const long long prof_t1 = clock64();
 #endif
   conv_epilogue_store<T, HT, COT>(p, acc, smem + wave * (NPL * 1024), n, h0, w0 + 32 * wave, cot, lane);
+#ifdef C8_PROFILE_WAIT
+  if (lane == 0 && p.dbg) {
+    long long* d = p.dbg + 3L * 8 * gridDim.x + ((long)blockIdx.x * 8 + wave) * 3;
+    d[0] = prof_t0 - prof_entry;           // prologue
+    d[1] = clock64() - prof_t1;            // epilogue up to the last store issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    d[2] = clock64() - prof_t1;            // ... up to the last store acknowledged
+  }
+#endif
 }
 
 // ---- chunk-granular variant for 3-row tiles (6-dye profiles): a kernel-column step of a 3-row tile is only ~16 MFMAs

@@ -24,7 +24,7 @@ int main() {
   p.y = y; p.y_planes_total = COUT / 16; p.y_plane0 = 0; p.y_nplanes = COUT / 16; p.y_gplanes = 1 << 30; p.y_wmul = 1;
   p.N = N; p.H = H; p.W = W; p.nchunk = CIN / 16; p.cout_pad = COUT; p.relu = 1;
 #ifdef C8_PROFILE_WAIT
-  const long nw = 2048L * 8; long long* dbg; hipMallocManaged(&dbg, nw * 3 * 8); memset(dbg, 0, nw * 3 * 8); p.dbg = dbg;
+  const long nw = 2048L * 8; long long* dbg; hipMallocManaged(&dbg, 2 * nw * 3 * 8); memset(dbg, 0, 2 * nw * 3 * 8); p.dbg = dbg;
 #endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
@@ -35,6 +35,8 @@ int main() {
 #ifdef C8_PROFILE_WAIT
     if (rep) { hipDeviceSynchronize(); double a = 0, b = 0, c = 0; double wl = 0; for (long i = 0; i < nw; ++i) { a += dbg[3*i]; b += (double)(dbg[3*i+1] >> 24); wl += (double)(dbg[3*i+1] & 0xffffff); c += dbg[3*i+2]; }
       printf("shader clock during the main loop: %.0f MHz (clock64 / wall_clock64 at 100 MHz)\n", c / wl * 100.0);
+      { double pr = 0, e1 = 0, e2 = 0; const long long* d2 = dbg + 3 * nw; for (long i = 0; i < nw; ++i) { pr += d2[3*i]; e1 += d2[3*i+1]; e2 += d2[3*i+2]; }
+        printf("per wave: prologue %.0f cycles, epilogue %.0f issued / %.0f acknowledged\n", pr / nw, e1 / nw, e2 / nw); }
       printf("per wave: main loop %.0f cycles, vmcnt wait %.1f%%, barrier %.1f%%\n", c / nw, 100 * a / c, 100 * b / c); }
 #endif
     if (rep) printf("conv8 %d->%d W=%d: %.1f us  %.1f TF/s nominal\n", CIN, COUT, W, ms * 1e3, 2.0 * N * H * W * CIN * COUT * 15 / ms / 1e9);
