@@ -33,7 +33,8 @@ static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype
   static const char* no8 = getenv("DN_TUNE_NO_CONV8");        // tuning aid: keep the 4-wave kernel everywhere
   // measured (N=256, W=4096 net): the 8-wave kernels win for 5-row tiles and for fp32; bf16 3-row tiles (6 dyes) are
   // faster on the 4-wave kernel at every level
-  v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && v.ht == 5));
+  static const char* ht3_8 = getenv("DN_TUNE_CONV8_HT3");      // tuning aid: 8-wave kernel for bf16 3-row tiles too
+  v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && (v.ht == 5 || ht3_8)));
   // Small batches (train.py's 16 profiles): the wide tiles leave CUs idle -- every 8-wave launch of the shipped net
   // is exactly 128 workgroups at N = 16.  Step down to the tile that still gives two workgroups per CU.
   if (p.N > 0) {
