@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int dh = tap / KW, dw = tap - dh * KW;
     tap_off[i] = __builtin_amdgcn_readfirstlane((dh * QW + dw) * 32);
   }
+  const bool last_tap_real = KSPLIT || wave + 4 * (WT - 1) < TAPS;   // wave-uniform
+  (void)last_tap_real;
   // bf16 fragment addressing (ds_read_b64_tr_b16): 16-lane group g reads pixels 8*(g>>1).. of plane (g&1)
   const int gpl_c = (lane >> 4) & 1;
   const int frag_off = gpl_c * DY_PS + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + 8 * (lane & 3);
@@ -246,7 +248,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         for (int k = it * PPI; k < (it + 1) * PPI && k < ST_ITERS; ++k) stage_piece(sc, k);
 #endif
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WT; ++i) {
+          // the repeated tap of the short wave: its fragments are read (no branch in the read stream) but the MFMAs,
+          // which are what the power budget pays for, are skipped
+          if (i + 1 == WT && !last_tap_real) continue;
 #pragma unroll
           for (int a = 0; a < NCOG; ++a)
 #pragma unroll
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
               acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[it & 1][a]),
                                                                      __builtin_bit_cast(bf16x8_t, bf[it & 1][i][c]),
                                                                      acc[i][a][c], 0, 0, 0);
+        }
       }
     } else {
       const int foff = (l31 & 7) * 4;                    // channel inside its plane
