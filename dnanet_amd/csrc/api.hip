@@ -35,6 +35,7 @@ static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype
   // faster on the 4-wave kernel at every level
   static const char* ht3_8 = getenv("DN_TUNE_CONV8_HT3");      // tuning aid: 8-wave kernel for bf16 3-row tiles too
   v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && (v.ht == 5 || ht3_8)));
+  if (p.stats) v.wave8 = false;      // fused BatchNorm statistics live in the 4-wave kernel's epilogue only
   // Small batches (train.py's 16 profiles): the wide tiles leave CUs idle -- every 8-wave launch of the shipped net
   // is exactly 128 workgroups at N = 16.  Step down to the tile that still gives two workgroups per CU.
   if (p.N > 0) {
@@ -88,22 +89,19 @@ int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, in
   return DN_OK;
 }
 
+static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
+                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream);
+
+int dn_conv2d_stats(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
+                    int dtype, float* partial, long partial_floats, int* ntiles, void* stream) {
+  DN_CHECK_ARG(partial && ntiles, "dn_conv2d_stats: null pointer");
+  DN_CHECK_ARG((kh == 3 && kw == 5) || (kh == 1 && kw == 3), "dn_conv2d_stats: kernel size (%d,%d) has no statistics epilogue", kh, kw);
+  return conv2d_impl(x, packed_w, bias, y, N, H, W, kh, kw, 0, dtype, partial, partial_floats, ntiles, stream);
+}
+
 int dn_conv2d(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
               int relu, int dtype, void* stream) {
-  DN_CHECK_ARG(x.base && packed_w && y.base, "dn_conv2d: null pointer");
-  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && x.channels > 0 && y.channels > 0, "dn_conv2d: bad shape N=%d H=%d W=%d", N, H, W);
-  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d: bad dtype %d", dtype);
-  const int xp = dn_planes(x.channels, dtype), yp = dn_planes(y.channels, dtype);
-  DN_CHECK_ARG(x.plane0 >= 0 && x.plane0 + xp <= x.planes_total, "dn_conv2d: x planes [%d,%d) outside buffer of %d",
-               x.plane0, x.plane0 + xp, x.planes_total);
-  DN_CHECK_ARG(y.plane0 >= 0 && y.plane0 + yp <= y.planes_total, "dn_conv2d: y planes [%d,%d) outside buffer of %d",
-               y.plane0, y.plane0 + yp, y.planes_total);
-  ConvParams p{};
-  p.x = x.base; p.x_planes_total = x.planes_total; p.x_plane0 = x.plane0; p.x_nplanes = xp; p.x_gplanes = 1 << 30; p.x_wmul = 1;
-  p.w = packed_w; p.bias = bias;
-  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
-  p.N = N; p.H = H; p.W = W; p.nchunk = xp; p.cout_pad = dn_channel_pad(y.channels); p.relu = relu;
-  return run_igemm(p, kh, kw, dtype, (hipStream_t)stream);
+  return conv2d_impl(x, packed_w, bias, y, N, H, W, kh, kw, relu, dtype, nullptr, 0, nullptr, stream);
 }
 
 int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2, dn_tensor y, int N, int H, int Win,
@@ -143,3 +141,30 @@ int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx
 }
 
 }  // extern "C"
+
+static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
+                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream) {
+  DN_CHECK_ARG(x.base && packed_w && y.base, "dn_conv2d: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && x.channels > 0 && y.channels > 0, "dn_conv2d: bad shape N=%d H=%d W=%d", N, H, W);
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d: bad dtype %d", dtype);
+  const int xp = dn_planes(x.channels, dtype), yp = dn_planes(y.channels, dtype);
+  DN_CHECK_ARG(x.plane0 >= 0 && x.plane0 + xp <= x.planes_total, "dn_conv2d: x planes [%d,%d) outside buffer of %d",
+               x.plane0, x.plane0 + xp, x.planes_total);
+  DN_CHECK_ARG(y.plane0 >= 0 && y.plane0 + yp <= y.planes_total, "dn_conv2d: y planes [%d,%d) outside buffer of %d",
+               y.plane0, y.plane0 + yp, y.planes_total);
+  ConvParams p{};
+  p.x = x.base; p.x_planes_total = x.planes_total; p.x_plane0 = x.plane0; p.x_nplanes = xp; p.x_gplanes = 1 << 30; p.x_wmul = 1;
+  p.w = packed_w; p.bias = bias;
+  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.N = N; p.H = H; p.W = W; p.nchunk = xp; p.cout_pad = dn_channel_pad(y.channels); p.relu = relu;
+  if (stats) {
+    p.stats = stats;
+    const ConvVariant v = choose_variant(p, kh, kw, dtype);
+    const long tiles = (long)N * ((H + v.ht - 1) / v.ht) * ((W + 127) / 128);
+    DN_CHECK_ARG(tiles * p.cout_pad * 2 <= stats_capacity, "dn_conv2d_stats: partial buffer of %ld floats, need %ld", stats_capacity,
+                 tiles * p.cout_pad * 2);
+    *ntiles = (int)tiles;
+  }
+  return run_igemm(p, kh, kw, dtype, (hipStream_t)stream);
+}
+

@@ -29,6 +29,7 @@ struct ConvParams {
   int cout_pad;             // multiple of COT
   int relu;
   int ntw, nth;             // column / row tiles per image
+  float* stats;             // BatchNorm partial sums [pixel tile][cout_pad][2] (STATS instantiations), else unused
 #ifdef C8_PROFILE_WAIT
   long long* dbg;           // [waves][3]: cycles in vmcnt waits, in barriers, total (scratch/conv8_micro.hip)
 #endif
@@ -56,7 +57,7 @@ template <> struct Mma32<float> {
 // with both.  The choice is per block, so the chunk loop exists in four compile-time variants and each block runs
 // one; inside a variant the MFMA loop has no branches, so the fragment reads and MFMAs of a whole chunk are
 // scheduled as one basic block.
-template <typename T, int KH, int KW, int HT, int COT>
+template <typename T, int KH, int KW, int HT, int COT, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
   constexpr int ROWS = HT + KH - 1;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   constexpr int ACT_BYTES = (ACT_RAW + 1023) / 1024 * 1024;          // weight image starts on a 1-KiB piece boundary
   constexpr int W_BYTES = TAPS * COT * 32;
   constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 4095) / 4096;      // wave-instructions of 1 KiB per wave
-  constexpr int EPI_BYTES = 4 * (COT / EPR) * 1024;                  // epilogue scratch: 4 waves x planes x 1 KiB
+  constexpr int EPI_BYTES = 4 * (32 / EPR) * 1024 + 4 * COT * 2 * 4;  // epilogue: 4 waves x one channel group + statistics
   constexpr int BUF_BYTES = ST_ITERS * 4096;
   // K chunks are software pipelined through NBUF LDS images when two workgroups of them fit a CU (1x1 / 1x3 kernels:
   // a chunk is only HT*NCG MFMAs per wave, far less than a load latency); the 3x5 images are too big for that and
@@ -91,6 +92,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const int cot = j % ncot;
   int pt = (j / ncot) * 8 + (blockIdx.x & 7);
   if (pt >= npt) return;                 // whole block: the grid is padded to a multiple of 8 pixel tiles
+  const int ptile = pt;
+  (void)ptile;
   const int tw = pt % p.ntw; pt /= p.ntw;
   const int th = pt % p.nth;
   const int n = pt / p.nth;
@@ -231,7 +234,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   // ---- epilogue: bias (+ folded BN) + ReLU in registers, then through a wave-private LDS scratch so that
   // every global store instruction writes 1 KiB of consecutive 16-byte pieces (32 pixels of one plane row)
   // instead of 8-byte fragments at a 32-byte stride.
-  constexpr int NPL = COT / EPR;                    // output planes of this tile
 #ifdef C8_PROFILE_WAIT
   if (lane == 0 && p.dbg) {
     long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 3;
@@ -240,73 +242,109 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land on the scratch (or outlive the wave)
   __syncthreads();                                  // all waves are done reading the staged tiles
-  unsigned char* scratch = smem_all + wave * (NPL * 1024);
   unsigned char* yb = (unsigned char*)p.y;
   const int yrow = p.W * p.y_wmul;
   const int wbase = w0 + 32 * wave;
-  // this lane's 16 bias values per channel group, fetched once (one batch of loads, one wait) instead of inside the
-  // row loop, where every row paid a load latency
-  float bias_r[NCG][16];
+  constexpr int GPL = 32 / EPR;                     // planes of one 32-channel group
+  unsigned char* scratch = smem_all + wave * (GPL * 1024);
+  float* stat_lds = (float*)(smem_all + 4 * GPL * 1024);            // [wave][COT][2], past every wave's scratch
+  const bool col_ok = wbase + l31 < p.W;
 #pragma unroll
-  for (int cg = 0; cg < NCG; ++cg)
+  for (int cg = 0; cg < NCG; ++cg) {
+    // this lane's 16 bias values of the group, fetched once (one batch of loads, one wait) -- inside the row loop
+    // every row paid a global-load latency
+    float bias_r[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      bias_r[cg][r] = p.bias ? p.bias[cot * COT + cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
+    for (int r = 0; r < 16; ++r) bias_r[r] = p.bias ? p.bias[cot * COT + cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
+    float ssum[STATS ? 16 : 1] = {}, ssq[STATS ? 16 : 1] = {};
 #pragma unroll
-  for (int hh = 0; hh < HT; ++hh) {
-    const int h = h0 + hh;
-    if (h < p.H) {                                  // block-uniform
-#pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) {
+    for (int hh = 0; hh < HT; ++hh) {
+      const int h = h0 + hh;
+      if (h < p.H) {                                  // block-uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int cl = cg * 32 + 8 * g + 4 * half;          // channel inside the tile
+          const int cl = 8 * g + 4 * half;            // channel inside the group
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            v[i] = acc[hh][cg][4 * g + i] + bias_r[cg][4 * g + i];
+            v[i] = acc[hh][cg][4 * g + i] + bias_r[4 * g + i];
             if (p.relu) v[i] = fmaxf(v[i], 0.f);
           }
           unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
           if constexpr (sizeof(T) == 4) {
             *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
+            __bf16 bq[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             uint2 u;
-            u.x = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
-            u.y = (uint32_t)__builtin_bit_cast(unsigned short, b2) | ((uint32_t)__builtin_bit_cast(unsigned short, b3) << 16);
+            u.x = (uint32_t)__builtin_bit_cast(unsigned short, bq[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[1]) << 16);
+            u.y = (uint32_t)__builtin_bit_cast(unsigned short, bq[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[3]) << 16);
             *(uint2*)dst = u;
+            if constexpr (STATS) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = (float)bq[i];     // statistics of the values as stored
+            }
+          }
+          if constexpr (STATS) {
+            if (col_ok) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { ssum[4 * g + i] += v[i]; ssq[4 * g + i] = fmaf(v[i], v[i], ssq[4 * g + i]); }
+            }
+          }
+        }
+#pragma unroll
+        for (int pl = 0; pl < GPL; ++pl) {
+          const int vplane = (cot * NCG + cg) * GPL + pl;
+          const int ygrp = vplane / p.y_gplanes;
+          const int yplane = vplane - ygrp * p.y_gplanes;
+          const int px = lane >> 1, pc = lane & 1;
+          const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
+#ifdef CV_ABLATE_NO_STORE
+          if (val.x == 0x12345678u)
+#endif
+          if (yplane < p.y_nplanes && wbase + px < p.W) {
+            const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
+                             (long)(wbase + px) * p.y_wmul + ygrp;
+            *(uint4*)(yb + rec * 32 + 16 * pc) = val;
           }
         }
       }
+    }
+    if constexpr (STATS) {
+      // sum over the 32 pixel lanes of each half-wave (xor masks < 32 stay inside a half), lane 0 / 32 keeps the totals
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        const int vplane = cot * NPL + pl;
-        const int ygrp = vplane / p.y_gplanes;
-        const int yplane = vplane - ygrp * p.y_gplanes;
-        const int px = lane >> 1, pc = lane & 1;
-        const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
-#ifdef CV_ABLATE_NO_STORE
-        if (val.x == 0x12345678u)
-#endif
-        if (yplane < p.y_nplanes && wbase + px < p.W) {
-          const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
-                           (long)(wbase + px) * p.y_wmul + ygrp;
-          *(uint4*)(yb + rec * 32 + 16 * pc) = val;
+      for (int r = 0; r < 16; ++r) {
+        float a = ssum[r], b = ssq[r];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (l31 == 0) {
+          const int ch = cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+          stat_lds[(wave * COT + ch) * 2] = a;
+          stat_lds[(wave * COT + ch) * 2 + 1] = b;
         }
       }
     }
   }
+  if constexpr (STATS) {
+    // BatchNorm statistics of this tile: partial[pixel tile][channel][sum, sum of squares] (bn_finalize_kernel's layout)
+    __syncthreads();
+    if (tid < COT * 2) {
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) t += stat_lds[wv * COT * 2 + tid];
+      p.stats[((long)ptile * p.cout_pad + cot * COT) * 2 + tid] = t;
+    }
+  }
 }
 
-template <typename T, int KH, int KW, int HT, int COT>
+template <typename T, int KH, int KW, int HT, int COT, bool STATS = false>
 int conv_igemm_launch(ConvParams p, hipStream_t stream) {
   p.ntw = (p.W + 127) / 128;
   p.nth = (p.H + HT - 1) / HT;
   const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / COT);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * p.x_wmul * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
-  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  if constexpr (STATS) hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

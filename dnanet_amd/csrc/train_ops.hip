@@ -482,20 +482,42 @@ extern "C" {
 
 int dn_reduce_blocks(long pixels) { return red_blocks(pixels); }
 
+static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                 float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream);
+
 int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                         float* scale, float* shift, float* partial, int dtype, void* stream) {
+  return bn_train_forward_impl(y, a, N, H, W, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                               partial, 0, dtype, stream);
+}
+
+int dn_bn_train_apply(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                      float* scale, float* shift, const float* partial, int ntiles, int dtype, void* stream) {
+  DN_CHECK_ARG(ntiles > 0, "dn_bn_train_apply: no partial statistics");
+  return bn_train_forward_impl(y, a, N, H, W, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                               (float*)partial, ntiles, dtype, stream);
+}
+
+// given_nblk > 0: `partial` already holds [given_nblk][cpad][2] sums (dn_conv2d_stats), the statistics pass is skipped
+static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                 float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream) {
   DN_CHECK_ARG(y.base && a.base && gamma && beta && mean && invstd && scale && shift && partial, "dn_bn_train_forward: null pointer");
   DN_CHECK_ARG(y.channels == a.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_forward: bad shape");
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
   DN_CHECK_ARG(HW * 2 < (1L << 31) && N < 65536 && nplanes < 65536, "dn_bn_train_forward: plane too large for the launch grid");
-  const int nblk = red_blocks((long)N * HW);
+  const int nblk = given_nblk > 0 ? given_nblk : red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
+  if (given_nblk <= 0) {
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(bn_stats_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), partial, cpad),
     hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), partial, cpad),
     "dn_bn_train_forward");
+  }
   DN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift);

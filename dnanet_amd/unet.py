@@ -279,15 +279,29 @@ class HipUNet(ParameterTree):
         """conv + bias -> y ; batch-stat BatchNorm + ReLU -> dst.  Saves what backward needs."""
         ws, cache = self._workspace(), self._train_cache
         y = PlaneBuffer(n, self._pp(u.cout), h, w, self.dtype, self.device)
-        self._conv(u, cache[u.conv], raw_x if u.cin == 1 else src, y.ref(u.cout), n, h, w, relu=0)
         cp = hip.channel_pad(u.cout)
         vec = torch.empty(4 * cp, dtype=torch.float32, device=self.device)
         mean, invstd, scale, shift = (vec[i * cp:(i + 1) * cp] for i in range(4))
-        hip.check(hip.lib.dn_bn_train_forward(
-            y.ref(u.cout), dst, n, h, w, hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(self.tensor(u.bn + ".bias")),
-            hip.ptr(self.tensor(u.bn + ".running_mean")), hip.ptr(self.tensor(u.bn + ".running_var")), BN_MOMENTUM, BN_EPS,
-            hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift), hip.ptr(ws["partial"]), self.dtype,
-            hip.stream_ptr()))
+        bn_args = (hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(self.tensor(u.bn + ".bias")),
+                   hip.ptr(self.tensor(u.bn + ".running_mean")), hip.ptr(self.tensor(u.bn + ".running_var")), BN_MOMENTUM, BN_EPS,
+                   hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift))
+        kh, kw = self.kernel_size
+        if u.cin != 1 and (kh, kw) in ((3, 5), (1, 3)) and self.profile is None:
+            # the batch statistics come out of the convolution's epilogue: one pass over y saved
+            need = n * ((h + 2) // 3) * ((w + 127) // 128) * cp * 2          # tiles are at least 3 rows x 128 columns
+            if ws.get("bnstat") is None or ws["bnstat"].numel() < need:
+                ws["bnstat"] = torch.empty(need, dtype=torch.float32, device=self.device)
+            ntiles = ctypes.c_int(0)
+            entry = cache[u.conv]
+            hip.check(hip.lib.dn_conv2d_stats(src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, kh, kw,
+                                              self.dtype, hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles),
+                                              hip.stream_ptr()))
+            hip.check(hip.lib.dn_bn_train_apply(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["bnstat"]), ntiles.value,
+                                                self.dtype, hip.stream_ptr()))
+        else:
+            self._conv(u, cache[u.conv], raw_x if u.cin == 1 else src, y.ref(u.cout), n, h, w, relu=0)
+            hip.check(hip.lib.dn_bn_train_forward(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["partial"]), self.dtype,
+                                                  hip.stream_ptr()))
         self._saved[u.conv] = {"y": y, "a": dst, "src": src, "mean": mean, "invstd": invstd, "scale": scale, "shift": shift,
                                "vec": vec, "n": n, "h": h, "w": w}
 

@@ -97,6 +97,16 @@ int dn_reduce_blocks(long pixels);
 int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                         float* scale, float* shift, float* partial, int dtype, void* stream);
+/* The convolution of a DoubleConv in training mode (nn.Conv2d + bias feeding nn.BatchNorm2d, unet_architecture.py:14-17)
+ * with the BatchNorm batch statistics taken in the convolution's epilogue: y as dn_conv2d(relu = 0), and per pixel tile
+ * and channel the sum and sum of squares of the values as stored, partial[tile][dn_channel_pad(cout)][2]
+ * (partial_floats = capacity of the buffer, *ntiles = tiles written).  Kernel sizes (3,5) and (1,3). */
+int dn_conv2d_stats(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
+                    int dtype, float* partial, long partial_floats, int* ntiles, void* stream);
+/* dn_bn_train_forward without its statistics pass: partial / ntiles come from dn_conv2d_stats. */
+int dn_bn_train_apply(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                      float* scale, float* shift, const float* partial, int ntiles, int dtype, void* stream);
 /* Backward of ReLU + BatchNorm2d (autograd of the above, trainable_unet.py:342): on entry g = dL/da,
  * on exit g = dL/dy (in place); dgamma/dbeta are written ([C]); coef: 3*dn_channel_pad(C) scratch.
  * scale/shift/mean/invstd are the vectors dn_bn_train_forward saved: the ReLU mask is recomputed as

@@ -142,6 +142,44 @@ def test_conv2d(gpu_device, case, dtype, ints):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(2, 32, 32, 5, 64, 3, 5), (3, 16, 24, 6, 200, 3, 5), (2, 64, 72, 5, 300, 3, 5),
+                                  (1, 32, 128, 3, 128, 3, 5), (2, 16, 40, 5, 130, 1, 3), (130, 32, 32, 5, 512, 3, 5)])
+def test_conv2d_stats(gpu_device, case, dtype):
+    """dn_conv2d_stats: same y as dn_conv2d without ReLU, and per-tile (sum, sum of squares) of the *stored* values
+    whose totals equal a separate pass over y (integer data: exact)."""
+    import ctypes
+    hip = _hip()
+    n, cin, cout, h, w, kh, kw = case
+    g = torch.Generator().manual_seed(11 + dtype)
+    x = torch.randint(-2, 3, (n, cin, h, w), generator=g).float()
+    wt = torch.randint(-1, 2, (cout, cin, kh, kw), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    ref = F.conv2d(x, wt, b, padding=(kh // 2, kw // 2))
+    xb = hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype)
+    packed = _pack(hip, wt, None, hip.PACK_FWD, dtype, gpu_device)
+    cp = hip.channel_pad(cout)
+    bias = _padvec(b, cp, gpu_device)
+    yb = hip.PlaneBuffer(n, hip.planes(cout, dtype), h, w, dtype, gpu_device, zero=True)
+    cap = n * ((h + 2) // 3) * ((w + 127) // 128) * cp * 2
+    stats = torch.full((cap,), float("nan"), device=gpu_device)
+    ntiles = ctypes.c_int(0)
+    hip.check(hip.lib.dn_conv2d_stats(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), yb.ref(cout), n, h, w, kh, kw, dtype,
+                                      hip.ptr(stats), cap, ctypes.byref(ntiles), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    y = yb.to_nchw(cout).cpu()
+    assert torch.equal(y, _q(ref, dtype))
+    t = ntiles.value
+    assert 0 < t and t * cp * 2 <= cap
+    part = stats[:t * cp * 2].view(t, cp, 2).double().sum(0).cpu()
+    assert torch.equal(part[:cout, 0], y.double().sum((0, 2, 3)))
+    assert torch.equal(part[:cout, 1], (y.double() ** 2).sum((0, 2, 3)))
+    assert float(part[cout:].abs().max()) == 0 if cp > cout else True
+    # too small a buffer is refused, not overrun
+    assert hip.lib.dn_conv2d_stats(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), yb.ref(cout), n, h, w, kh, kw, dtype,
+                                   hip.ptr(stats), 16, ctypes.byref(ntiles), hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 32, 32, 5, 64, 3, 5), (1, 64, 32, 6, 96, 3, 5), (2, 16, 24, 5, 40, 1, 3)])
 def test_conv2d_dgrad(gpu_device, case, dtype):
     hip = _hip()
