@@ -428,7 +428,9 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__
 // ---- Adam (coupled L2) + zero_grad ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_over_bc1, float inv_sqrt_bc2,
-                                                   float beta1, float beta2, float eps, float wd, float gscale, int zero_grad) {
+                                                   float beta1, float beta2, float eps, float wd, float gscale, int zero_grad,
+                                                   const float* __restrict__ hyper) {
+  if (hyper) { lr_over_bc1 = hyper[1]; inv_sqrt_bc2 = hyper[2]; }   // graph replay: the step-dependent scalars live in HBM
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float pv = p[i];
     const float gv = fmaf(wd, pv, g[i] * gscale);
@@ -438,6 +440,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     v[i] = vv;
     p[i] = pv - lr_over_bc1 * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
     if (zero_grad) g[i] = 0.f;
+  }
+}
+
+// Step counter and bias corrections on the device, so that a captured launch sequence (HIP graph) can be replayed:
+// hyper = [lr (written by the host when it changes), lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)], t = ++*step.
+__global__ void adam_hyper_kernel(float* hyper, long long* step, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    hyper[1] = (float)((double)hyper[0] / bc1);
+    hyper[2] = (float)(1.0 / sqrt(bc2));
   }
 }
 
@@ -679,7 +693,19 @@ int dn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
   DN_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "dn_adam_step: bad argument");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
-                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale, zero_grad);
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale, zero_grad,
+                     (const float*)nullptr);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+int dn_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float* hyper, long long* step,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, void* stream) {
+  DN_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && hyper && step && n > 0, "dn_adam_step_graph: bad argument");
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, step, beta1, beta2);
+  DN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
+                     0.f, 0.f, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, (const float*)hyper);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

@@ -61,6 +61,7 @@ _SIGS = {
     "dn_dice_forward": (c_int, [_P, _P, c_long, _P, _P, _P]),
     "dn_dice_backward": (c_int, [_P, _P, c_long, _P, _P, _P]),
     "dn_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_long, c_float, c_int, _P]),
+    "dn_adam_step_graph": (c_int, [_P, _P, _P, _P, c_long, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "dn_i16_to_f32": (c_int, [_P, _P, c_long, _P]),
     "dn_conv2d_variant": (c_int, [c_int] * 8 + [ctypes.c_char_p, c_int]),
     "dn_conv2d_stats": (c_int, [DnTensor, _P, _P, DnTensor, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, POINTER(c_int), _P]),

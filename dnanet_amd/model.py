@@ -26,7 +26,7 @@ from . import hip
 from .allele_caller import NearestBasePairCaller
 from .data import chunks
 from .prediction import Prediction
-from .unet import ExponentialLR, HipAdam, HipUNet
+from .unet import ExponentialLR, GraphedTrainStep, HipAdam, HipUNet
 
 LOGGER = logging.getLogger("dnanet")
 TORCH_DEFAULT_DEVICE = "cuda" if torch.cuda.is_available() else "cpu"     # base.py:11
@@ -126,6 +126,28 @@ class _Loss:
         return self
 
 
+class _ResidentSet:
+    """A dataset tensorised once and kept in HBM; batches are contiguous slices (views) when the images come in
+    dataset order, otherwise one ``index_select``."""
+
+    def __init__(self, images: Sequence, inputs: torch.Tensor, targets: torch.Tensor):
+        self._images = list(images)                          # keeps the ids alive
+        self._index = {id(im): i for i, im in enumerate(self._images)}
+        self._arrays = {"inputs": inputs, "targets": targets}
+
+    def gather(self, images: Sequence, what: str) -> Optional[torch.Tensor]:
+        try:
+            idx = [self._index[id(im)] for im in images]
+        except KeyError:
+            return None
+        if not idx:
+            return None
+        arr = self._arrays[what]
+        if idx == list(range(idx[0], idx[0] + len(idx))):
+            return arr[idx[0]:idx[0] + len(idx)]
+        return arr.index_select(0, torch.tensor(idx, device=arr.device))
+
+
 class DNANet_UNet(TrainableModel):
     def __init__(self, depth: int, kernel_size: Tuple[int, int], num_filters: int = 64, device: Optional[str] = None,
                  apply_allele_caller: Optional[bool] = True, dtype: str = "fp32"):
@@ -136,6 +158,8 @@ class DNANet_UNet(TrainableModel):
         self._model = HipUNet(depth, tuple(kernel_size), num_filters, self._device, dtype=dtype)
         self.loss_fn = self._dice
         self.allele_caller = NearestBasePairCaller() if apply_allele_caller else None
+        self._resident: Optional[_ResidentSet] = None
+        self._graph = {"enabled": False, "step": None, "warm": False}
 
     # ---- tensorisation (trainable_unet.py:60-89) ---------------------------------------------------
     @staticmethod
@@ -145,6 +169,10 @@ class DNANet_UNet(TrainableModel):
     def get_inputs(self, images: Sequence) -> torch.Tensor:
         """(N,1,H,W) fp32 on the device.  int16-representable data crosses PCIe as int16 (half the bytes,
         one copy for the whole batch) and is widened on the GPU."""
+        if self._resident is not None:
+            hit = self._resident.gather(images, "inputs")
+            if hit is not None:
+                return hit
         arr = np.stack([np.asarray(im.data) for im in images])               # (N,H,W,1)
         arr = np.ascontiguousarray(np.transpose(arr, (0, 3, 1, 2)))
         if arr.dtype.kind in "iu" and arr.size and int(arr.min()) >= -32768 and int(arr.max()) <= 32767:
@@ -155,9 +183,39 @@ class DNANet_UNet(TrainableModel):
         return torch.from_numpy(arr.astype(np.float32, copy=False)).to(self._device)
 
     def get_targets(self, images: Sequence) -> torch.Tensor:
+        if self._resident is not None:
+            hit = self._resident.gather(images, "targets")
+            if hit is not None:
+                return hit
         arr = np.stack([np.asarray(im.annotation.image) for im in images])   # (N,H,W,1)
         arr = np.ascontiguousarray(np.transpose(arr, (0, 3, 1, 2)))
         return torch.from_numpy(arr).to(self._device)
+
+    def make_resident(self, *datasets, limit_bytes: int = 16 << 30) -> bool:
+        """Input pipeline: tensorise the given datasets ONCE and keep them in HBM (348 profiles =
+        35 MB), so a training step gathers its batch on the device instead of stacking numpy arrays and crossing
+        PCIe (``trainable_unet.py:60-89`` does that per step).  Images are matched by identity; a batch with an
+        unknown image simply takes the per-step path.  ``fit`` calls this for its training / validation sets and
+        drops the copy when it returns; image data must not be modified in between."""
+        self.release_resident()
+        images = [im for ds in datasets if ds is not None for im in ds]
+        if not images or self._model.device.type != "cuda":
+            return False
+        try:
+            first_x, first_t = np.asarray(images[0].data), np.asarray(images[0].annotation.image)
+            total = len(images) * (first_x.size * 4 + first_t.size * first_t.dtype.itemsize)
+            if total > limit_bytes:
+                return False
+            step = 1024
+            xs = torch.cat([self.get_inputs(images[i:i + step]) for i in range(0, len(images), step)])
+            ts = torch.cat([self.get_targets(images[i:i + step]) for i in range(0, len(images), step)])
+        except (AttributeError, ValueError, TypeError):   # ragged shapes, images without annotation, ...
+            return False
+        self._resident = _ResidentSet(images, xs, ts)
+        return True
+
+    def release_resident(self):
+        self._resident = None
 
     # ---- loss ------------------------------------------------------------------------------------------
     def _dice(self, logits: torch.Tensor, targets: torch.Tensor) -> _Loss:
@@ -200,6 +258,30 @@ class DNANet_UNet(TrainableModel):
         steps_per_epoch_val = len(validation_set) // batch_size if validation_set else None
         prev_best = (1., 0)
         best_validation_loss = float("inf")
+        self.make_resident(dataset, validation_set)
+        # Small batches are bound by the host issuing ~330 launches per step: replay them from a HIP graph
+        # (``hip_graph=True/False`` overrides; large batches gain nothing and would pin their activations).
+        use_graph = kwargs.pop("hip_graph", None)
+        if use_graph is None:
+            use_graph = batch_size <= 64
+        self._graph = {"enabled": bool(use_graph) and self._model.device.type == "cuda", "step": None, "warm": False,
+                       "batch_size": batch_size}
+        try:
+            self._fit_epochs(dataset, validation_set, num_epochs, steps_per_epoch, steps_per_epoch_val, batch_size, optimizer,
+                             scheduler, metrics, writer, save_best, checkpoint_dir, min_delta, prev_best, best_validation_loss)
+        finally:
+            self.release_resident()
+            self._graph = {"enabled": False, "step": None, "warm": False}
+        if writer:
+            writer.close()
+        if save_best:
+            self.load(checkpoint_dir / "best_model")
+            shutil.rmtree(checkpoint_dir / "best_model")
+            LOGGER.info("Restored previous best model")
+
+    def _fit_epochs(self, dataset, validation_set, num_epochs, steps_per_epoch, steps_per_epoch_val, batch_size, optimizer,
+                    scheduler, metrics, writer, save_best, checkpoint_dir, min_delta, prev_best, best_validation_loss):
+        """The epoch loop of ``fit`` (``trainable_unet.py:177-287``)."""
         for epoch in range(num_epochs):
             summary: Dict[str, Dict[str, float]] = defaultdict(dict)
             descr = f"Epoch {epoch + 1}/{num_epochs}"
@@ -240,12 +322,6 @@ class DNANet_UNet(TrainableModel):
                 for tag, scalars in summary.items():
                     writer.add_scalars(tag, scalars, global_step=epoch + 1)
                 writer.flush()
-        if writer:
-            writer.close()
-        if save_best:
-            self.load(checkpoint_dir / "best_model")
-            shutil.rmtree(checkpoint_dir / "best_model")
-            LOGGER.info("Restored previous best model")
 
     def set_up_metrics(self, use_evaluation_metric: bool) -> List[BinaryAccuracy]:
         return [BinaryAccuracy()] if use_evaluation_metric else []
@@ -267,16 +343,46 @@ class DNANet_UNet(TrainableModel):
         for metric in metrics or []:
             metric.reset()
         epoch_loss = 0.
+        pending = None       # the loss of step k is read back after step k+1 is queued: the GPU never waits for the host
         for step, batch in enumerate(batches):
-            loss = self.step(batch, metrics)
-            if train:
-                loss.backward()
-                optimizer.step()
-                optimizer.zero_grad()
-            epoch_loss = (epoch_loss * step + float(loss)) / (step + 1)
-            if _tqdm is not None and isinstance(batches, _tqdm):
-                batches.set_postfix({("training" if train else "validation") + "_loss": epoch_loss})
+            loss = self._graphed_train_step(batch, metrics, optimizer) if train else None
+            if loss is None:
+                loss = self.step(batch, metrics)
+                if train:
+                    loss.backward()
+                    optimizer.step()
+                    optimizer.zero_grad()
+            if pending is not None:
+                epoch_loss = (epoch_loss * (step - 1) + float(pending)) / step
+                if _tqdm is not None and isinstance(batches, _tqdm):
+                    batches.set_postfix({("training" if train else "validation") + "_loss": epoch_loss})
+            pending, last = loss, step
+        if pending is not None:
+            epoch_loss = (epoch_loss * last + float(pending)) / (last + 1)
         return epoch_loss
+
+    def _graphed_train_step(self, batch: Sequence, metrics, optimizer: HipAdam) -> Optional[_Loss]:
+        """step + backward + optimizer.step + zero_grad as one HIP-graph replay; None when this batch has to take the
+        launch-by-launch path (graphs off, first step = warm-up of every lazily built workspace, odd batch size)."""
+        cfg = self._graph
+        if not cfg["enabled"] or len(batch) != cfg.get("batch_size"):
+            return None
+        if not cfg["warm"]:
+            cfg["warm"] = True
+            return None
+        inputs, y_true = self.get_inputs(batch), self.get_targets(batch)
+        if cfg["step"] is None or not cfg["step"].matches(inputs) or cfg["step"].optimizer is not optimizer:
+            count = optimizer.step_count
+            try:
+                cfg["step"] = GraphedTrainStep(self._model, optimizer, inputs, y_true)
+            except Exception as exc:      # capture refused: keep training launch by launch (still on the GPU)
+                LOGGER.warning(f"HIP graph capture of the training step failed ({exc}); continuing without it")
+                optimizer.step_count = count
+                self._model._saved = None
+                cfg["enabled"], cfg["step"] = False, None
+                return None
+        sums = cfg["step"](inputs, y_true)
+        return _Loss(self._model, sums, inputs.numel(), metrics)
 
     def step(self, batch: Sequence, metrics: Optional[Sequence[BinaryAccuracy]]) -> _Loss:
         inputs = self.get_inputs(batch)

@@ -473,13 +473,22 @@ class HipAdam:
         self.step_count = 0
         self._zeroed = False
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, device_state: Optional[Sequence[torch.Tensor]] = None):
+        """``device_state = (hyper, step)``: learning rate, bias corrections and step count are read from / kept in
+        device memory (``dn_adam_step_graph``), which is what lets ``GraphedTrainStep`` replay this launch."""
         g = self.param_groups[0]
         self.step_count += 1
         m = self.model
-        hip.check(hip.lib.dn_adam_step(hip.ptr(m.flat_params), hip.ptr(m.flat_grads), hip.ptr(self.exp_avg),
-                                       hip.ptr(self.exp_avg_sq), m.flat_params.numel(), g["lr"], g["betas"][0], g["betas"][1],
-                                       g["eps"], g["weight_decay"], self.step_count, grad_scale, 1, hip.stream_ptr()))
+        if device_state is None:
+            hip.check(hip.lib.dn_adam_step(hip.ptr(m.flat_params), hip.ptr(m.flat_grads), hip.ptr(self.exp_avg),
+                                           hip.ptr(self.exp_avg_sq), m.flat_params.numel(), g["lr"], g["betas"][0], g["betas"][1],
+                                           g["eps"], g["weight_decay"], self.step_count, grad_scale, 1, hip.stream_ptr()))
+        else:
+            hyper, step = device_state
+            hip.check(hip.lib.dn_adam_step_graph(hip.ptr(m.flat_params), hip.ptr(m.flat_grads), hip.ptr(self.exp_avg),
+                                                 hip.ptr(self.exp_avg_sq), m.flat_params.numel(), hip.ptr(hyper), hip.ptr(step),
+                                                 g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], grad_scale, 1,
+                                                 hip.stream_ptr()))
         m._param_epoch += 1
         self._zeroed = True
 
@@ -487,6 +496,67 @@ class HipAdam:
         if not self._zeroed:
             self.model.flat_grads.zero_()
         self._zeroed = False
+
+
+class GraphedTrainStep:
+    """One whole training step -- weight re-packing, train-mode forward, Dice, backward, Adam, zero_grad: ~330 kernel
+    launches for the shipped net -- captured once into a HIP graph and replayed.  At train.py's batch of 16 the step is
+    otherwise bound by the host issuing those launches (trainable_unet.py:339-347 is the loop being replaced).
+
+    Batch shape, betas / eps / weight decay are frozen into the graph (``matches`` tells whether a batch fits); the
+    learning rate and the Adam step count live in device memory, so ExponentialLR keeps working.  The activations of
+    the step stay allocated in the graph's private pool (~70 MB per bf16 profile)."""
+
+    def __init__(self, model: "HipUNet", optimizer: HipAdam, x: torch.Tensor, t: torch.Tensor):
+        self.model, self.optimizer = model, optimizer
+        g = optimizer.param_groups[0]
+        self._frozen = (tuple(x.shape), tuple(g["betas"]), g["eps"], g["weight_decay"])
+        self.x = x.detach().clone().contiguous()
+        self.t = t.detach().to(torch.int8).contiguous().clone()
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=model.device)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=model.device)
+        self._lr_dev, self._step_expected = None, None
+        model.train()
+        model._train_cache = None                          # the re-packing of the weights must be part of the graph
+        model._workspace()
+        self.graph = torch.cuda.CUDAGraph()
+        saved_count, saved_epoch = optimizer.step_count, model._param_epoch
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph):
+            logits = model.forward_train(self.x)
+            self.sums = model.dice_forward(logits, self.t)
+            model.backward()
+            optimizer.step(device_state=(self.hyper, self.step_dev))
+            optimizer.zero_grad()
+        # capture executed nothing: undo the host-side bookkeeping it did
+        optimizer.step_count, model._param_epoch = saved_count, saved_epoch
+        self._cache = model._train_cache                   # packed images written by the graph: keep them alive
+        model._train_cache = None
+
+    def matches(self, x: torch.Tensor) -> bool:
+        g = self.optimizer.param_groups[0]
+        return self._frozen == (tuple(x.shape), tuple(g["betas"]), g["eps"], g["weight_decay"])
+
+    def __call__(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """Runs one step on (x, t); returns a snapshot of the Dice sums vector (``HipUNet.dice_forward``)."""
+        if not self.matches(x):
+            raise ValueError("batch shape or optimizer constants differ from the captured step")
+        opt, m = self.optimizer, self.model
+        lr = float(opt.param_groups[0]["lr"])
+        if lr != self._lr_dev:
+            self.hyper[0:1].fill_(lr)
+            self._lr_dev = lr
+        if self._step_expected != opt.step_count:          # someone stepped the optimizer outside the graph
+            self.step_dev.fill_(opt.step_count)
+        self.x.copy_(x, non_blocking=True)
+        self.t.copy_(t, non_blocking=True)
+        self.graph.replay()
+        opt.step_count += 1
+        self._step_expected = opt.step_count
+        m._param_epoch += 2                                 # running statistics and parameters were rewritten
+        m._train_cache = None
+        m._saved = None
+        return self.sums.clone()
 
 
 class ExponentialLR:

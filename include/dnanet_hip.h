@@ -146,6 +146,12 @@ int dn_dice_backward(const float* logits, const signed char* targets, long n, co
  * grads are scaled by grad_scale first and zeroed afterwards when zero_grad != 0 (optimizer.zero_grad(), :344). */
 int dn_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, long step, float grad_scale, int zero_grad, void* stream);
+/* The same Adam step for a caller that replays a captured launch sequence (HIP graph): everything that changes from step
+ * to step lives in device memory.  *step (device) is incremented, hyper[0] (device) is the learning rate the host writes
+ * when the ExponentialLR schedule changes it (trainable_unet.py:159-162,305-311); hyper[1..2] receive the bias-correction
+ * scalars.  beta / eps / weight_decay are launch constants. */
+int dn_adam_step_graph(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float* hyper, long long* step,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, void* stream);
 /* int16 RFU -> fp32 (get_input, trainable_unet.py:70-72). */
 int dn_i16_to_f32(const short* in, float* out, long n, void* stream);
 

@@ -147,3 +147,66 @@ def test_data_parallel_step_world1_equals_plain_step(gpu_device):
         assert abs(results[0][1] - results[1][1]) < 1e-7
     finally:
         dist.destroy_process_group()
+
+
+def test_resident_dataset_batches_equal_per_step_tensorisation(gpu_device):
+    """Input pipeline: batches gathered from the HBM-resident copy are the tensors get_inputs /
+    get_targets build from the images themselves -- in dataset order (a view), shuffled (a gather), and a batch
+    holding an unknown image falls back to the per-step path."""
+    from dnanet_amd.model import DNANet_UNet
+    from dnanet_amd.synthetic import make_batch
+    x, t = make_batch(7, 5, 256, seed=9, unique=7)
+    images = _images(x, t)
+    model = DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False)
+    plain = [(model.get_inputs(b).clone(), model.get_targets(b).clone())
+             for b in (images[2:5], [images[6], images[0], images[3]])]
+    assert model.make_resident(images[:4], images[4:])
+    for (px, pt), b in zip(plain, (images[2:5], [images[6], images[0], images[3]])):
+        rx, rt = model.get_inputs(b), model.get_targets(b)
+        assert rx.dtype == px.dtype and rt.dtype == pt.dtype and torch.equal(rx, px) and torch.equal(rt, pt)
+    stranger = _images(x[:1] + 1, t[:1])[0]
+    mixed = model.get_inputs([images[1], stranger])
+    assert torch.equal(mixed[0], plain[0][0][0] * 0 + model.get_inputs([images[1]])[0]) and float(mixed[1, 0, 0, 0]) == x[0, 0, 0, 0] + 1
+    model.release_resident()
+    assert model._resident is None
+
+
+def test_fit_hip_graph_replay_equals_launch_by_launch(gpu_device, caplog):
+    """fit() replays the whole training step from a HIP graph for small batches; parameters, running statistics and
+    the reported losses equal the launch-by-launch loop (the kernels are deterministic; the only difference allowed
+    is the device-side pow() of Adam's bias correction)."""
+    import logging
+    from dnanet_amd import unet as U
+    from dnanet_amd.model import DNANet_UNet
+    from dnanet_amd.synthetic import make_batch
+    x, t = make_batch(9, 5, 256, seed=4, unique=9)
+    images = _images(x, t)
+    states, losses, replays = [], [], []
+    real_call = U.GraphedTrainStep.__call__
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        model = DNANet_UNet(3, (3, 5), 8, device="cuda", apply_allele_caller=False)
+        count = [0]
+
+        def counting(self, *a, _c=count, **k):
+            _c[0] += 1
+            return real_call(self, *a, **k)
+        U.GraphedTrainStep.__call__ = counting
+        try:
+            with caplog.at_level(logging.INFO, logger="dnanet"):
+                caplog.clear()
+                model.fit(images, batch_size=4, num_epochs=3, learning_rate=2e-3, use_scheduler=True, hip_graph=use_graph)
+                losses.append([r.getMessage() for r in caplog.records if "Training loss" in r.getMessage()])
+        finally:
+            U.GraphedTrainStep.__call__ = real_call
+        replays.append(count[0])
+        states.append({k: v.detach().cpu().clone() for k, v in model._model.state_dict().items()})
+    assert replays == [0, 5]                      # 2 steps x 3 epochs, the very first one is the eager warm-up
+    assert len(losses[0]) == 3
+    for a, b in zip(losses[0], losses[1]):
+        assert abs(float(a.split()[-1]) - float(b.split()[-1])) < 1e-5
+    for k, v in states[0].items():
+        if v.dtype == torch.int64:
+            assert int(v) == int(states[1][k]) == 6, k
+        else:
+            assert torch.allclose(states[1][k], v, rtol=1e-5, atol=1e-7), k
