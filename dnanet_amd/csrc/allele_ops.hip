@@ -55,6 +55,33 @@ __global__ __launch_bounds__(AL_THREADS) void allele_runs_kernel(const float* __
   }
 }
 
+// Pixel confusion counts of one profile per block (pixel_metrics.py:9-74): a pixel is predicted positive when
+// p >= thr_ge (precision / recall / F1) resp. p > thr_gt (IoU); truth is 1 / 0, anything else counts for neither class.
+// counts[image] = { tp, fp, fn } for ">=" followed by { tp, fp, fn } for ">".  Integer sums: order independent.
+__global__ __launch_bounds__(256) void pixel_confusion_kernel(const float* __restrict__ probs, const signed char* __restrict__ truth,
+                                                              long pixels, float thr_ge, float thr_gt, int* __restrict__ counts) {
+  const float* p = probs + (long)blockIdx.x * pixels;
+  const signed char* t = truth + (long)blockIdx.x * pixels;
+  int c[6] = {0, 0, 0, 0, 0, 0};
+  for (long i = threadIdx.x; i < pixels; i += 256) {
+    const float pv = p[i];
+    const int one = t[i] == 1, zero = t[i] == 0;
+    const int ge = pv >= thr_ge, gt = pv > thr_gt;
+    c[0] += ge & one; c[1] += ge & zero; c[2] += (ge ^ 1) & one;
+    c[3] += gt & one; c[4] += gt & zero; c[5] += (gt ^ 1) & one;
+  }
+  __shared__ int red[4][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int v = c[k];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) counts[blockIdx.x * 6 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" {
@@ -74,5 +101,16 @@ int dn_call_alleles(const float* probs, const float* rfu, const double* scaler, 
   DN_LAUNCH_CHECK();
   return DN_OK;
 }
+
+int dn_pixel_confusion(const float* probs, const signed char* truth, int n_images, long pixels, float thr_ge, float thr_gt,
+                       int* counts, void* stream) {
+  DN_CHECK_ARG(probs && truth && counts, "dn_pixel_confusion: null pointer");
+  DN_CHECK_ARG(n_images > 0 && pixels > 0 && pixels < (1L << 31), "dn_pixel_confusion: bad shape %d x %ld", n_images, pixels);
+  hipLaunchKernelGGL(pixel_confusion_kernel, dim3(n_images), dim3(256), 0, (hipStream_t)stream, probs, truth, pixels, thr_ge,
+                     thr_gt, counts);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
 
 }  // extern "C"

@@ -141,33 +141,79 @@ __global__ __launch_bounds__(256) void head_kernel(const unsigned char* x, int x
 // weight packing: canonical fp32 parameter -> [nchunk][taps][rows_pad][EPR] of T
 // ------------------------------------------------------------------------------------------------
 template <typename T>
+__device__ __forceinline__ void pack_element(const float* __restrict__ w, const float* __restrict__ scale, void* out, int cout,
+                                             int cin, int taps, int mode, int rows_pad, int nchunk, int gsize, long i) {
+  constexpr int EPR = RecTraits<T>::EPR;
+  if (mode >= DN_PACK_VEC) {                   // fp32 side images
+    float v = 0.f;
+    if (mode == DN_PACK_VEC) {                 // [rows_pad]
+      if (i < cout) v = w[i];
+    } else if (mode == DN_PACK_UP_BIAS) {      // [2][gsize]
+      const int co = (int)(i % gsize);
+      if (co < cout) v = w[co];
+    } else {                                   // DN_PACK_FIRST: [taps][rows_pad]
+      const int co = (int)(i % rows_pad), tap = (int)(i / rows_pad);
+      if (co < cout) v = w[(long)co * taps + tap] * (scale ? scale[co] : 1.f);
+    }
+    ((float*)out)[i] = v;
+    return;
+  }
+  const int e = (int)(i % EPR);
+  long r = i / EPR;
+  const int row = (int)(r % rows_pad); r /= rows_pad;
+  const int tap = (int)(r % taps);
+  const int ck = (int)(r / taps);
+  float v = 0.f;
+  if (mode == DN_PACK_FWD) {                 // rows = co, K = ci
+    const int co = row, ci = ck * EPR + e;
+    if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + tap] * (scale ? scale[co] : 1.f);
+  } else if (mode == DN_PACK_DGRAD) {        // rows = ci, K = co, taps flipped
+    const int ci = row, co = ck * EPR + e;
+    if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + (taps - 1 - tap)];
+  } else if (mode == DN_PACK_CONVT_FWD) {    // w: [cin][cout][1][2]; rows = k*gsize + co, K = ci
+    const int k = row / gsize, co = row % gsize, ci = ck * EPR + e;
+    if (k < 2 && co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
+  } else {                                   // DN_PACK_CONVT_DGRAD: rows = ci, K = (k, co) virtual planes
+    const int gpl = gsize / EPR;
+    const int k = ck / gpl, co = (ck % gpl) * EPR + e, ci = row;
+    if (k < 2 && co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
+  }
+  ((T*)out)[i] = dn_from_float<T>(v);
+}
+
+template <typename T>
+__host__ __device__ inline long pack_total(int taps, int mode, int rows_pad, int nchunk, int gsize) {
+  if (mode == DN_PACK_VEC) return rows_pad;
+  if (mode == DN_PACK_UP_BIAS) return 2L * gsize;
+  if (mode == DN_PACK_FIRST) return (long)taps * rows_pad;
+  return (long)nchunk * taps * rows_pad * RecTraits<T>::EPR;
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                                           T* out, int cout, int cin, int taps, int mode, int rows_pad,
                                                           int nchunk, int gsize) {
-  constexpr int EPR = RecTraits<T>::EPR;
-  const long total = (long)nchunk * taps * rows_pad * EPR;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(i % EPR);
-    long r = i / EPR;
-    const int row = (int)(r % rows_pad); r /= rows_pad;
-    const int tap = (int)(r % taps);
-    const int ck = (int)(r / taps);
-    float v = 0.f;
-    if (mode == DN_PACK_FWD) {                 // rows = co, K = ci
-      const int co = row, ci = ck * EPR + e;
-      if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + tap] * (scale ? scale[co] : 1.f);
-    } else if (mode == DN_PACK_DGRAD) {        // rows = ci, K = co, taps flipped
-      const int ci = row, co = ck * EPR + e;
-      if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + (taps - 1 - tap)];
-    } else if (mode == DN_PACK_CONVT_FWD) {    // w: [cin][cout][1][2]; rows = k*gsize + co, K = ci
-      const int k = row / gsize, co = row % gsize, ci = ck * EPR + e;
-      if (k < 2 && co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
-    } else {                                   // DN_PACK_CONVT_DGRAD: rows = ci, K = (k, co) virtual planes
-      const int gpl = gsize / EPR;
-      const int k = ck / gpl, co = (ck % gpl) * EPR + e, ci = row;
-      if (k < 2 && co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
-    }
-    out[i] = dn_from_float<T>(v);
+  const long total = pack_total<T>(taps, mode, rows_pad, nchunk, gsize);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    pack_element<T>(w, scale, out, cout, cin, taps, mode, rows_pad, nchunk, gsize, i);
+}
+
+// every image of a job table in one launch: block -> job by binary search on the jobs' first blocks
+constexpr int PACK_BLOCK_ELEMS = 2048;
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batched_kernel(const dn_pack_job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const dn_pack_job j = jobs[lo];
+  const long total = pack_total<T>(j.taps, j.mode, j.rows_pad, j.nchunk, j.gsize);
+  const long base = (long)((int)blockIdx.x - j.block0) * PACK_BLOCK_ELEMS;
+#pragma unroll
+  for (int k = 0; k < PACK_BLOCK_ELEMS / 256; ++k) {
+    const long i = base + k * 256 + threadIdx.x;
+    if (i < total) pack_element<T>(j.w, j.scale, j.out, j.cout, j.cin, j.taps, j.mode, j.rows_pad, j.nchunk, j.gsize, i);
   }
 }
 
@@ -252,6 +298,48 @@ int dn_pack_weight(const float* w, const float* scale, void* packed, int cout, i
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, scale, (float*)packed,
                        cout, cin, taps, mode, rows_pad, nchunk, gsize);
   else return dn_set_error(DN_ERR_ARG, "dn_pack_weight: bad dtype %d", dtype);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+static int pack_geometry(int cout, int cin, int mode, int epr, int* rows_pad, int* nchunk, int* gsize, int* taps) {
+  *gsize = dn_channel_pad(cout);
+  if (mode == DN_PACK_FWD) { *rows_pad = dn_channel_pad(cout); *nchunk = (cin + epr - 1) / epr; }
+  else if (mode == DN_PACK_DGRAD) { *rows_pad = dn_channel_pad(cin); *nchunk = (cout + epr - 1) / epr; }
+  else if (mode == DN_PACK_CONVT_FWD) { *rows_pad = 2 * *gsize; *nchunk = (cin + epr - 1) / epr; *taps = 1; }
+  else if (mode == DN_PACK_CONVT_DGRAD) { *rows_pad = dn_channel_pad(cin); *nchunk = 2 * (*gsize / epr); *taps = 1; }
+  else if (mode == DN_PACK_VEC || mode == DN_PACK_UP_BIAS || mode == DN_PACK_FIRST) { *rows_pad = *gsize; *nchunk = 1; }
+  else return -1;
+  return 0;
+}
+
+long dn_pack_jobs_prepare(dn_pack_job* jobs, int njobs, int dtype) {
+  if (!jobs || njobs <= 0 || (dtype != DN_BF16 && dtype != DN_F32)) { dn_set_error(DN_ERR_ARG, "dn_pack_jobs_prepare: bad argument"); return -1; }
+  const int epr = dtype == DN_BF16 ? 16 : 8;
+  long block = 0;
+  for (int i = 0; i < njobs; ++i) {
+    dn_pack_job& j = jobs[i];
+    if (!j.w || !j.out || j.cout <= 0 || j.cin <= 0 || j.taps <= 0 ||
+        pack_geometry(j.cout, j.cin, j.mode, epr, &j.rows_pad, &j.nchunk, &j.gsize, &j.taps)) {
+      dn_set_error(DN_ERR_ARG, "dn_pack_jobs_prepare: job %d is malformed (mode %d)", i, j.mode);
+      return -1;
+    }
+    const long total = dtype == DN_BF16 ? pack_total<__bf16>(j.taps, j.mode, j.rows_pad, j.nchunk, j.gsize)
+                                        : pack_total<float>(j.taps, j.mode, j.rows_pad, j.nchunk, j.gsize);
+    j.block0 = (int)block;
+    block += (total + PACK_BLOCK_ELEMS - 1) / PACK_BLOCK_ELEMS;
+    if (block > 0x7fffffffL) { dn_set_error(DN_ERR_ARG, "dn_pack_jobs_prepare: too many blocks"); return -1; }
+  }
+  return block;
+}
+
+int dn_pack_batched(const dn_pack_job* jobs_device, int njobs, long grid_blocks, int dtype, void* stream) {
+  DN_CHECK_ARG(jobs_device && njobs > 0 && grid_blocks > 0 && grid_blocks <= 0x7fffffffL, "dn_pack_batched: bad argument");
+  if (dtype == DN_BF16)
+    hipLaunchKernelGGL(pack_batched_kernel<__bf16>, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+  else if (dtype == DN_F32)
+    hipLaunchKernelGGL(pack_batched_kernel<float>, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+  else return dn_set_error(DN_ERR_ARG, "dn_pack_batched: bad dtype %d", dtype);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

@@ -13,12 +13,19 @@ import torch
 
 F32, BF16 = 0, 1
 PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
+PACK_VEC, PACK_UP_BIAS, PACK_FIRST = 4, 5, 6          # fp32 side images, dn_pack_batched only
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdnanet_hip.so")
 
 
 class DnTensor(Structure):
     _fields_ = [("base", c_void_p), ("planes_total", c_int), ("plane0", c_int), ("channels", c_int)]
+
+
+class DnPackJob(Structure):
+    """``dn_pack_job`` of include/dnanet_hip.h."""
+    _fields_ = [("w", c_void_p), ("scale", c_void_p), ("out", c_void_p), ("cout", c_int), ("cin", c_int), ("taps", c_int),
+                ("mode", c_int), ("rows_pad", c_int), ("nchunk", c_int), ("gsize", c_int), ("block0", c_int)]
 
 
 class HipError(RuntimeError):
@@ -63,6 +70,9 @@ _SIGS = {
     "dn_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_long, c_float, c_int, _P]),
     "dn_adam_step_graph": (c_int, [_P, _P, _P, _P, c_long, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "dn_i16_to_f32": (c_int, [_P, _P, c_long, _P]),
+    "dn_pack_jobs_prepare": (c_long, [_P, c_int, c_int]),
+    "dn_pack_batched": (c_int, [_P, c_int, c_long, c_int, _P]),
+    "dn_pixel_confusion": (c_int, [_P, _P, c_int, c_long, c_float, c_float, _P, _P]),
     "dn_conv2d_variant": (c_int, [c_int] * 8 + [ctypes.c_char_p, c_int]),
     "dn_conv2d_stats": (c_int, [DnTensor, _P, _P, DnTensor, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, POINTER(c_int), _P]),
     "dn_bn_train_apply": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,

@@ -18,6 +18,10 @@ def _confusion(images: Sequence, predictions: Sequence, threshold: float = 0.5, 
     reference, which compares ``== 1`` and ``== 0``)."""
     out = np.zeros(3, dtype=np.int64)
     for image, prediction in zip(images, predictions):
+        device = _device_counts(image, prediction, threshold, strict)
+        if device is not None:
+            out += device
+            continue
         truth = np.asarray(image.annotation.image)
         prob = np.asarray(prediction.image)
         pos = prob > threshold if strict else prob >= threshold
@@ -25,6 +29,15 @@ def _confusion(images: Sequence, predictions: Sequence, threshold: float = 0.5, 
         out[1] += np.count_nonzero(pos & (truth == 0))
         out[2] += np.count_nonzero(~pos & (truth == 1))
     return out
+
+
+def _device_counts(image, prediction, threshold: float, strict: bool):
+    """{tp, fp, fn} that ``DNANet_UNet.predict_batch`` already counted on the GPU for exactly this (image, prediction)
+    pair and threshold, else None."""
+    tag = getattr(prediction, "_pixel_counts", None)
+    if tag is None or tag[0] != id(image) or tag[1] != threshold:
+        return None
+    return np.asarray(tag[2][3:6] if strict else tag[2][0:3], dtype=np.int64)
 
 
 def pixel_precision(images: Sequence, predictions: Sequence) -> float:
@@ -45,10 +58,14 @@ def pixel_f1_score(images: Sequence, predictions: Sequence) -> float:
 def average_binary_iou(images: Sequence, predictions: Sequence, threshold: float = 0.5) -> float:
     total, n = 0.0, 0
     for image, prediction in zip(images, predictions):
-        truth = np.asarray(image.annotation.image, dtype=np.float64)
-        pred = (np.asarray(prediction.image) > threshold).astype(np.float64)
-        inter = float(np.sum(truth * pred))
-        union = float(np.sum(truth) + np.sum(pred) - inter)
+        device = _device_counts(image, prediction, threshold, strict=True)
+        if device is not None:           # 0/1 masks: intersection = tp, union = tp + fp + fn
+            inter, union = float(device[0]), float(device.sum())
+        else:
+            truth = np.asarray(image.annotation.image, dtype=np.float64)
+            pred = (np.asarray(prediction.image) > threshold).astype(np.float64)
+            inter = float(np.sum(truth * pred))
+            union = float(np.sum(truth) + np.sum(pred) - inter)
         if union > 0:
             total += inter / union
         n += 1

@@ -404,6 +404,10 @@ class DNANet_UNet(TrainableModel):
         host = probs.movedim(1, -1).cpu().numpy()                      # (N,H,W,1): one D->H copy for the batch
         predictions = [Prediction(image=host[i], meta={"original_image_path": getattr(image, "path", None)})
                        for i, image in enumerate(batch)]
+        counts = self._pixel_counts(batch, probs)
+        if counts is not None:       # annotated profiles: the pixel metrics' confusion counts from the same pass
+            for i, pred in enumerate(predictions):
+                pred._pixel_counts = (id(batch[i]), 0.5, tuple(int(c) for c in counts[i]))
         if self.allele_caller:
             LOGGER.info("Calling alleles from predicted segmentation...")
             if hasattr(self.allele_caller, "call_alleles_batch"):
@@ -412,6 +416,24 @@ class DNANet_UNet(TrainableModel):
             else:
                 predictions = [self.allele_caller.call_alleles(im, pred) for im, pred in zip(batch, predictions)]
         return predictions
+
+    def _pixel_counts(self, batch: Sequence, probs: torch.Tensor) -> Optional[np.ndarray]:
+        """On-device metrics: per profile {tp, fp, fn} at ``p >= 0.5`` and at ``p > 0.5`` against the
+        annotation, computed from the probability maps while they are in HBM (``dn_pixel_confusion``).  Only for
+        batches whose every annotation is a 0/1 mask of the output's shape; otherwise None and
+        ``dnanet_amd.metrics`` makes its boolean passes on the host, like the reference."""
+        try:
+            truth = np.stack([np.asarray(im.annotation.image) for im in batch])              # (N,H,W,1)
+        except (AttributeError, ValueError, TypeError):
+            return None
+        if truth.size != probs.numel() or truth.dtype.kind not in "iubf" or not np.isin(truth, (0, 1)).all():
+            return None
+        truth = np.ascontiguousarray(np.transpose(truth, (0, 3, 1, 2)).astype(np.int8))
+        truth_dev = torch.from_numpy(truth).to(probs.device)
+        counts = torch.empty((len(batch), 6), dtype=torch.int32, device=probs.device)
+        hip.check(hip.lib.dn_pixel_confusion(hip.ptr(probs), hip.ptr(truth_dev), len(batch), probs[0].numel(), 0.5, 0.5,
+                                             hip.ptr(counts), hip.stream_ptr()))
+        return counts.cpu().numpy()
 
     def predict_raw(self, images: Sequence) -> torch.Tensor:
         return self._model(self.get_inputs(images))

@@ -252,27 +252,61 @@ class HipUNet(ParameterTree):
 
     @torch.no_grad()
     def _build_train_cache(self):
-        """Packed GEMM images of the current weights (forward and data-gradient forms)."""
-        cache: Dict[str, dict] = {}
-        for u in self.conv_units:
-            w = self.tensor(u.conv + ".weight")
-            entry = {"bias": self._padvec(self.tensor(u.conv + ".bias"))}
-            if u.cin == 1:
-                kh, kw = self.kernel_size
-                wf = torch.zeros((kh * kw, hip.channel_pad(u.cout)), dtype=torch.float32, device=self.device)
-                wf[:, :u.cout] = w.reshape(u.cout, kh * kw).t()
-                entry["wf"] = wf
-            else:
-                wv = self._virtual_weight(u, w)
-                entry["w"] = self._pack(wv, None, hip.PACK_FWD)
-                entry["wd"] = self._pack(wv, None, hip.PACK_DGRAD)
-            cache[u.conv] = entry
-        for up in self.up_units:
-            w = self.tensor(up.name + ".weight")
-            cache[up.name] = {"w": self._pack(w, None, hip.PACK_CONVT_FWD), "wd": self._pack(w, None, hip.PACK_CONVT_DGRAD),
-                              "bias": self._up_bias2(self.tensor(up.name + ".bias"))}
-        cache["head_w"] = self._padvec(self.tensor("outputs.weight"))
-        self._train_cache = cache
+        """Packed GEMM images of the current weights (forward and data-gradient forms), padded biases, the first
+        convolution's tap-major weights.  The images live in buffers allocated once; a job table on the device
+        (``dn_pack_job``) lets ONE launch refresh all of them -- the weights change every training step."""
+        key = (self.dtype, self.flat_params.data_ptr())
+        if self._train_cache is None or self._train_cache.get("_key") != key:
+            cache: Dict[str, dict] = {"_key": key}
+            jobs: List[hip.DnPackJob] = []
+            kh, kw = self.kernel_size
+
+            def job(w: torch.Tensor, out: torch.Tensor, cout: int, cin: int, taps: int, mode: int) -> torch.Tensor:
+                jobs.append(hip.DnPackJob(hip.ptr(w), None, hip.ptr(out), cout, cin, taps, mode, 0, 0, 0, 0))
+                return out
+
+            def image(w: torch.Tensor, mode: int) -> torch.Tensor:
+                if mode in (hip.PACK_FWD, hip.PACK_DGRAD):
+                    cout, cin, th, tw = w.shape
+                else:
+                    cin, cout, th, tw = w.shape[0], w.shape[1], 1, 2
+                nbytes = hip.lib.dn_packed_weight_bytes(cout, cin, th, tw, mode, self.dtype)
+                return job(w, torch.empty(nbytes, dtype=torch.uint8, device=self.device), cout, cin, th * tw, mode)
+
+            def floats(n: int) -> torch.Tensor:
+                return torch.empty(n, dtype=torch.float32, device=self.device)
+
+            for u in self.conv_units:
+                w, b = self.tensor(u.conv + ".weight"), self.tensor(u.conv + ".bias")
+                entry = {"bias": job(b, floats(hip.channel_pad(u.cout)), u.cout, 1, 1, hip.PACK_VEC)}
+                if u.cin == 1:
+                    entry["wf"] = job(w, floats(kh * kw * hip.channel_pad(u.cout)), u.cout, 1, kh * kw,
+                                      hip.PACK_FIRST).view(kh * kw, hip.channel_pad(u.cout))
+                elif u.split and u.split % hip.epr(self.dtype):
+                    entry["_virtual"] = u           # concat halves that do not fill whole planes: widened copy per build
+                else:
+                    entry["w"], entry["wd"] = image(w, hip.PACK_FWD), image(w, hip.PACK_DGRAD)
+                cache[u.conv] = entry
+            for up in self.up_units:
+                w, b = self.tensor(up.name + ".weight"), self.tensor(up.name + ".bias")
+                cache[up.name] = {"w": image(w, hip.PACK_CONVT_FWD), "wd": image(w, hip.PACK_CONVT_DGRAD),
+                                  "bias": job(b, floats(2 * hip.channel_pad(b.numel())), b.numel(), 1, 1, hip.PACK_UP_BIAS)}
+            hw = self.tensor("outputs.weight")
+            cache["head_w"] = job(hw, floats(hip.channel_pad(hw.numel())), hw.numel(), 1, 1, hip.PACK_VEC)
+            table = (hip.DnPackJob * len(jobs))(*jobs)
+            blocks = hip.lib.dn_pack_jobs_prepare(table, len(jobs), self.dtype)
+            if blocks < 0:
+                hip.check(1)
+            raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).clone()
+            cache["_jobs"] = (raw.to(self.device), len(jobs), blocks)
+            self._train_cache = cache
+        cache = self._train_cache
+        jobs_dev, njobs, blocks = cache["_jobs"]
+        hip.check(hip.lib.dn_pack_batched(hip.ptr(jobs_dev), njobs, blocks, self.dtype, hip.stream_ptr()))
+        for entry in cache.values():
+            if isinstance(entry, dict) and "_virtual" in entry:
+                wv = self._virtual_weight(entry["_virtual"], self.tensor(entry["_virtual"].conv + ".weight"))
+                entry["w"], entry["wd"] = self._pack(wv, None, hip.PACK_FWD), self._pack(wv, None, hip.PACK_DGRAD)
         self._train_cache_version = self._versions()
 
     def _unit_forward(self, u: ConvUnit, src, dst, n, h, w, raw_x=None):
@@ -517,8 +551,9 @@ class GraphedTrainStep:
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=model.device)
         self._lr_dev, self._step_expected = None, None
         model.train()
-        model._train_cache = None                          # the re-packing of the weights must be part of the graph
         model._workspace()
+        model._build_train_cache()                         # job table and image buffers exist before the capture ...
+        model._train_cache_version = None                  # ... and the re-packing launch itself is part of the graph
         self.graph = torch.cuda.CUDAGraph()
         saved_count, saved_epoch = optimizer.step_count, model._param_epoch
         torch.cuda.synchronize()
@@ -530,8 +565,8 @@ class GraphedTrainStep:
             optimizer.zero_grad()
         # capture executed nothing: undo the host-side bookkeeping it did
         optimizer.step_count, model._param_epoch = saved_count, saved_epoch
-        self._cache = model._train_cache                   # packed images written by the graph: keep them alive
-        model._train_cache = None
+        self._cache = model._train_cache                   # the images the graph writes: keep them alive
+        model._train_cache_version = None
 
     def matches(self, x: torch.Tensor) -> bool:
         g = self.optimizer.param_groups[0]
@@ -554,7 +589,6 @@ class GraphedTrainStep:
         opt.step_count += 1
         self._step_expected = opt.step_count
         m._param_epoch += 2                                 # running statistics and parameters were rewritten
-        m._train_cache = None
         m._saved = None
         return self.sums.clone()
 

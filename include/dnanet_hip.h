@@ -31,6 +31,10 @@ extern "C" {
 #define DN_PACK_DGRAD 1        /* same weight, flipped/transposed, for the data gradient */
 #define DN_PACK_CONVT_FWD 2    /* ConvTranspose2d weight [Cin][Cout][1][2] as a 1x1 GEMM to 2*Cout */
 #define DN_PACK_CONVT_DGRAD 3  /* its data gradient: 1x1 GEMM from the two output columns to Cin */
+/* fp32 side images, only through dn_pack_batched: */
+#define DN_PACK_VEC 4          /* a [cout] vector (bias, head weight) zero-padded to dn_channel_pad(cout) floats */
+#define DN_PACK_UP_BIAS 5      /* ConvTranspose2d bias [cout] -> [2][dn_channel_pad(cout)], repeated per output column */
+#define DN_PACK_FIRST 6        /* first conv weight [cout][1][KH][KW] -> [KH*KW][dn_channel_pad(cout)] floats */
 
 typedef struct dn_tensor {
   void* base;        /* device pointer to the buffer */
@@ -52,6 +56,20 @@ long dn_packed_weight_bytes(int cout, int cin, int kh, int kw, int mode, int dty
  * w' = w * gamma / sqrt(running_var + eps). */
 int dn_pack_weight(const float* w, const float* scale, void* packed, int cout, int cin, int kh, int kw, int mode,
                    int dtype, void* stream);
+
+/* All the images a training step needs, re-packed by ONE launch (the weights change every step; 40+ separate launches
+ * cost more than the packing at small batches).  jobs: device copy of an array prepared by dn_pack_jobs_prepare,
+ * which fills the derived fields (taps = kh*kw goes in; rows_pad, nchunk, gsize, block0 come out) and returns the
+ * grid size, or -1 on a bad mode.  Pointers are device pointers and must stay valid for every later launch. */
+typedef struct dn_pack_job {
+  const float* w;        /* canonical fp32 parameter */
+  const float* scale;    /* nullable, [cout]: folded BatchNorm scale (DN_PACK_FWD, DN_PACK_FIRST) */
+  void* out;             /* packed image (dtype for modes 0-3, fp32 for modes 4-6) */
+  int cout, cin, taps, mode;
+  int rows_pad, nchunk, gsize, block0;
+} dn_pack_job;
+long dn_pack_jobs_prepare(dn_pack_job* jobs_host, int njobs, int dtype);
+int dn_pack_batched(const dn_pack_job* jobs_device, int njobs, long grid_blocks, int dtype, void* stream);
 
 /* Name of the kernel instantiation dn_conv2d dispatches a (cin -> cout, N x H x W, kh x kw) convolution to, e.g.
  * "conv_igemm8<bf16,3x5,ht5,cot64>".  No counterpart in the reference (torch picks its cuDNN / MIOpen algorithm
@@ -166,6 +184,13 @@ int dn_i16_to_f32(const short* in, float* out, long n, void* stream);
 int dn_call_alleles(const float* probs, const float* rfu, const double* scaler, long scaler_stride, const double* table_bp,
                     const int* table_order, const int* table_off, int N, int H, int W, int amax, int* out_rfu, int* out_first,
                     void* stream);
+
+/* Pixel metrics (DNAnet/evaluation/segmentation/pixel_metrics.py:9-74) from the probability maps still in HBM: per
+ * profile counts[i][0..2] = { tp, fp, fn } with "predicted positive" = p >= thr_ge (pixel_precision / recall / F1,
+ * :17-36), counts[i][3..5] the same with p > thr_gt (average_binary_iou, :65).  truth: int8, 1 / 0, other values count
+ * for neither class.  probs, truth: [n_images][pixels]. */
+int dn_pixel_confusion(const float* probs, const signed char* truth, int n_images, long pixels, float thr_ge, float thr_gt,
+                       int* counts, void* stream);
 
 #ifdef __cplusplus
 }

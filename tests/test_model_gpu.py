@@ -210,3 +210,33 @@ def test_fit_hip_graph_replay_equals_launch_by_launch(gpu_device, caplog):
             assert int(v) == int(states[1][k]) == 6, k
         else:
             assert torch.allclose(states[1][k], v, rtol=1e-5, atol=1e-7), k
+
+
+def test_device_pixel_counts_equal_host_metrics(gpu_device):
+    """the confusion counts predict_batch takes on the GPU give the same pixel metrics as the
+    reference-style boolean passes over the host copies (integers: exact), including pixels at exactly 0.5."""
+    from dnanet_amd import metrics as M
+    from dnanet_amd.model import DNANet_UNet
+    from dnanet_amd.prediction import Prediction
+    from dnanet_amd.synthetic import make_batch
+    x, t = make_batch(6, 5, 256, seed=21, unique=6)
+    rng = np.random.default_rng(0)
+    t = (rng.random(t.shape) < 0.2).astype(np.int8)          # plenty of positives so every count is non-trivial
+    images = _images(x, t)
+    torch.manual_seed(3)
+    model = DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False)
+    preds = model.predict_batch(images)
+    assert all(hasattr(p, "_pixel_counts") for p in preds)
+    bare = [Prediction(image=p.image, meta=p.meta) for p in preds]
+    for name, fn in M.METRICS.items():
+        assert fn(images=images, predictions=preds) == fn(images=images, predictions=bare), name
+    # the kernel itself on crafted values: 0.5 is positive for ">=" and negative for ">"
+    from dnanet_amd import hip
+    probs = torch.tensor([[0.5, 0.5, 0.7, 0.2, 0.49999997, 0.9, 0.1, 0.5]], device="cuda")
+    truth = torch.tensor([[1, 0, 1, 1, 0, 0, 0, 2]], dtype=torch.int8, device="cuda")
+    counts = torch.zeros((1, 6), dtype=torch.int32, device="cuda")
+    hip.check(hip.lib.dn_pixel_confusion(hip.ptr(probs), hip.ptr(truth), 1, 8, 0.5, 0.5, hip.ptr(counts), hip.stream_ptr()))
+    assert counts.cpu().tolist() == [[2, 2, 1, 1, 1, 2]]
+    # annotations that are not 0/1 masks: no device counts, host path as before
+    images[0].annotation.image = images[0].annotation.image.astype(np.float64) * 0.5
+    assert not any(hasattr(p, "_pixel_counts") for p in model.predict_batch(images))

@@ -430,3 +430,52 @@ def test_dice_and_adam(gpu_device):
         torch.cuda.synchronize()
         assert float(gd.abs().max()) == 0.0
     assert torch.allclose(pd.cpu(), ref.data, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_pack_batched_equals_single_packs(gpu_device, dtype):
+    """dn_pack_batched (one launch for a whole job table) writes the images dn_pack_weight writes one by one, and the
+    fp32 side images (padded vector, doubled up-conv bias, tap-major first-conv weight)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(3)
+    w1 = torch.randn(40, 24, 3, 5, generator=g).to(gpu_device)
+    w2 = torch.randn(64, 32, 1, 2, generator=g).to(gpu_device)          # ConvTranspose2d layout [cin][cout][1][2]
+    b = torch.randn(40, generator=g).to(gpu_device)
+    wf = torch.randn(24, 1, 3, 5, generator=g).to(gpu_device)
+    specs = [(w1, 40, 24, 15, hip.PACK_FWD), (w1, 40, 24, 15, hip.PACK_DGRAD), (w2, 32, 64, 2, hip.PACK_CONVT_FWD),
+             (w2, 32, 64, 2, hip.PACK_CONVT_DGRAD), (b, 40, 1, 1, hip.PACK_VEC), (b, 40, 1, 1, hip.PACK_UP_BIAS),
+             (wf, 24, 1, 15, hip.PACK_FIRST)]
+    outs, jobs = [], []
+    for w, cout, cin, taps, mode in specs:
+        if mode <= hip.PACK_CONVT_DGRAD:
+            kh, kw = (3, 5) if taps == 15 else (1, 2)
+            n = hip.lib.dn_packed_weight_bytes(cout, cin, kh, kw, mode, dtype)
+        else:
+            cp = hip.channel_pad(cout)
+            n = 4 * {hip.PACK_VEC: cp, hip.PACK_UP_BIAS: 2 * cp, hip.PACK_FIRST: taps * cp}[mode]
+        out = torch.full((n + 64,), 0xAB, dtype=torch.uint8, device=gpu_device)      # guard bytes behind every image
+        outs.append((out, n))
+        jobs.append(hip.DnPackJob(hip.ptr(w), None, hip.ptr(out), cout, cin, taps, mode, 0, 0, 0, 0))
+    table = (hip.DnPackJob * len(jobs))(*jobs)
+    blocks = hip.lib.dn_pack_jobs_prepare(table, len(jobs), dtype)
+    assert blocks > 0
+    dev = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).clone().to(gpu_device)
+    hip.check(hip.lib.dn_pack_batched(hip.ptr(dev), len(jobs), blocks, dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    for (w, cout, cin, taps, mode), (out, n) in zip(specs, outs):
+        assert bool((out[n:] == 0xAB).all()), mode
+        if mode <= hip.PACK_CONVT_DGRAD:
+            ref = _pack(hip, w, None, mode, dtype, gpu_device)
+            assert torch.equal(out[:n], ref.view(torch.uint8).reshape(-1)), mode
+        else:
+            got = out[:n].view(torch.float32).cpu()
+            cp = hip.channel_pad(cout)
+            if mode == hip.PACK_VEC:
+                want = torch.zeros(cp); want[:cout] = w.cpu()
+            elif mode == hip.PACK_UP_BIAS:
+                want = torch.zeros(2, cp); want[:, :cout] = w.cpu(); want = want.reshape(-1)
+            else:
+                want = torch.zeros(taps, cp); want[:, :cout] = w.cpu().reshape(cout, taps).t(); want = want.reshape(-1)
+            assert torch.equal(got, want), mode
+    bad = (hip.DnPackJob * 1)(hip.DnPackJob(hip.ptr(b), None, hip.ptr(outs[0][0]), 40, 1, 1, 9, 0, 0, 0, 0))
+    assert hip.lib.dn_pack_jobs_prepare(bad, 1, dtype) == -1
