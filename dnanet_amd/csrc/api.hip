@@ -35,7 +35,8 @@ static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype
   // faster on the 4-wave kernel at every level
   static const char* ht3_8 = getenv("DN_TUNE_CONV8_HT3");      // tuning aid: 8-wave kernel for bf16 3-row tiles too
   v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && (v.ht == 5 || ht3_8)));
-  if (p.stats) v.wave8 = false;      // fused BatchNorm statistics live in the 4-wave kernel's epilogue only
+  static const char* stats4 = getenv("DN_TUNE_STATS_4WAVE");   // tuning aid: fused-statistics convolutions on the 4-wave kernel
+  if (p.stats && stats4) v.wave8 = false;
   // Small batches (train.py's 16 profiles): the wide tiles leave CUs idle -- every 8-wave launch of the shipped net
   // is exactly 128 workgroups at N = 16.  Step down to the tile that still gives two workgroups per CU.
   if (p.N > 0) {
@@ -160,7 +161,7 @@ static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_
   if (stats) {
     p.stats = stats;
     const ConvVariant v = choose_variant(p, kh, kw, dtype);
-    const long tiles = (long)N * ((H + v.ht - 1) / v.ht) * ((W + 127) / 128);
+    const long tiles = (long)N * ((H + v.ht - 1) / v.ht) * (v.wave8 ? W / 256 : (W + 127) / 128);   // one partial per block tile
     DN_CHECK_ARG(tiles * p.cout_pad * 2 <= stats_capacity, "dn_conv2d_stats: partial buffer of %ld floats, need %ld", stats_capacity,
                  tiles * p.cout_pad * 2);
     *ntiles = (int)tiles;

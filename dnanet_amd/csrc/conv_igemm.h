@@ -52,6 +52,103 @@ template <> struct Mma32<float> {
   }
 };
 
+// Epilogue shared by the 4-wave and 8-wave kernels: bias (+ folded BN) + ReLU in registers, then through a wave-private
+// LDS scratch so that every global store instruction writes 1 KiB of consecutive 16-byte pieces (32 pixels of one
+// plane row) instead of 8-byte fragments at a 32-byte stride.  A lane's bias values are fetched once, before the rows.
+// Plain form: one pass over the rows, all COT channels of a row per scratch round trip (COT/EPR KiB per wave).
+// STATS form: one pass per 32-channel group, so that a lane holds only 16 running (sum, sum of squares) pairs of the
+// values AS STORED (bf16-rounded) -- BatchNorm's batch statistics; they end up in stat_wave[channel of the tile][2]
+// (LDS, this wave's).
+template <typename T, int HT, int COT, bool STATS>
+__device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_t (&acc)[HT][COT / 32], unsigned char* scratch,
+                                                    float* stat_wave, int n, int h0, int wbase, int cot, int lane) {
+  constexpr int NCG = COT / 32, EPR = RecTraits<T>::EPR, GPL = 32 / EPR;
+  constexpr int NPASS = STATS ? NCG : 1, CPP = NCG / NPASS;        // passes over the rows, channel groups per pass
+  const int l31 = lane & 31, half = lane >> 5;
+  unsigned char* yb = (unsigned char*)p.y;
+  const int yrow = p.W * p.y_wmul;
+  const bool col_ok = wbase + l31 < p.W;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    float bias_r[CPP][16];
+#pragma unroll
+    for (int c = 0; c < CPP; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        bias_r[c][r] = p.bias ? p.bias[cot * COT + (ps * CPP + c) * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
+    float ssum[STATS ? 16 : 1] = {}, ssq[STATS ? 16 : 1] = {};
+#pragma unroll
+    for (int hh = 0; hh < HT; ++hh) {
+      const int h = h0 + hh;
+      if (h < p.H) {                                  // block-uniform
+#pragma unroll
+        for (int c = 0; c < CPP; ++c) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = c * 32 + 8 * g + 4 * half;   // channel inside the pass
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              v[i] = acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i];
+              if (p.relu) v[i] = fmaxf(v[i], 0.f);
+            }
+            unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
+            if constexpr (sizeof(T) == 4) {
+              *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              __bf16 bq[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              uint2 u;
+              u.x = (uint32_t)__builtin_bit_cast(unsigned short, bq[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[1]) << 16);
+              u.y = (uint32_t)__builtin_bit_cast(unsigned short, bq[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[3]) << 16);
+              *(uint2*)dst = u;
+              if constexpr (STATS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (float)bq[i];     // statistics of the values as stored
+              }
+            }
+            if constexpr (STATS) {
+              if (col_ok) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ssum[4 * g + i] += v[i]; ssq[4 * g + i] = fmaf(v[i], v[i], ssq[4 * g + i]); }
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int pl = 0; pl < CPP * GPL; ++pl) {
+          const int vplane = (cot * NCG + ps * CPP) * GPL + pl;
+          const int ygrp = vplane / p.y_gplanes;
+          const int yplane = vplane - ygrp * p.y_gplanes;
+          const int px = lane >> 1, pc = lane & 1;
+          const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
+#ifdef CV_ABLATE_NO_STORE
+          if (val.x == 0x12345678u)
+#endif
+          if (yplane < p.y_nplanes && wbase + px < p.W) {
+            const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
+                             (long)(wbase + px) * p.y_wmul + ygrp;
+            *(uint4*)(yb + rec * 32 + 16 * pc) = val;
+          }
+        }
+      }
+    }
+    if constexpr (STATS) {
+      // sum over the 32 pixel lanes of each half-wave (xor masks < 32 stay inside a half), lane 0 / 32 keeps the totals
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = ssum[r], b = ssq[r];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        if (l31 == 0) {
+          const int ch = ps * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+          stat_wave[ch * 2] = a;
+          stat_wave[ch * 2 + 1] = b;
+        }
+      }
+    }
+  }
+}
+
 // A tile whose halo row lies above / below the image (every tile of the shipped 5-dye case, half the tiles of the
 // 6-dye one) leaves out the MFMAs of the (kernel row, output row) pairs that only see that zero row: 2 of 15 for 3x5
 // with both.  The choice is per block, so the chunk loop exists in four compile-time variants and each block runs
@@ -68,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   constexpr int ACT_BYTES = (ACT_RAW + 1023) / 1024 * 1024;          // weight image starts on a 1-KiB piece boundary
   constexpr int W_BYTES = TAPS * COT * 32;
   constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 4095) / 4096;      // wave-instructions of 1 KiB per wave
-  constexpr int EPI_BYTES = 4 * (32 / EPR) * 1024 + 4 * COT * 2 * 4;  // epilogue: 4 waves x one channel group + statistics
+  constexpr int EPI_BYTES = 4 * (COT / EPR) * 1024 + 4 * COT * 2 * 4;  // epilogue: 4 waves x COT channels + statistics
   constexpr int BUF_BYTES = ST_ITERS * 4096;
   // K chunks are software pipelined through NBUF LDS images when two workgroups of them fit a CU (1x1 / 1x3 kernels:
   // a chunk is only HT*NCG MFMAs per wave, far less than a load latency); the 3x5 images are too big for that and
@@ -242,88 +339,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may land on the scratch (or outlive the wave)
   __syncthreads();                                  // all waves are done reading the staged tiles
-  unsigned char* yb = (unsigned char*)p.y;
-  const int yrow = p.W * p.y_wmul;
-  const int wbase = w0 + 32 * wave;
-  constexpr int GPL = 32 / EPR;                     // planes of one 32-channel group
-  unsigned char* scratch = smem_all + wave * (GPL * 1024);
-  float* stat_lds = (float*)(smem_all + 4 * GPL * 1024);            // [wave][COT][2], past every wave's scratch
-  const bool col_ok = wbase + l31 < p.W;
-#pragma unroll
-  for (int cg = 0; cg < NCG; ++cg) {
-    // this lane's 16 bias values of the group, fetched once (one batch of loads, one wait) -- inside the row loop
-    // every row paid a global-load latency
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias_r[r] = p.bias ? p.bias[cot * COT + cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
-    float ssum[STATS ? 16 : 1] = {}, ssq[STATS ? 16 : 1] = {};
-#pragma unroll
-    for (int hh = 0; hh < HT; ++hh) {
-      const int h = h0 + hh;
-      if (h < p.H) {                                  // block-uniform
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = 8 * g + 4 * half;            // channel inside the group
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[hh][cg][4 * g + i] + bias_r[4 * g + i];
-            if (p.relu) v[i] = fmaxf(v[i], 0.f);
-          }
-          unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
-          if constexpr (sizeof(T) == 4) {
-            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            __bf16 bq[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            uint2 u;
-            u.x = (uint32_t)__builtin_bit_cast(unsigned short, bq[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[1]) << 16);
-            u.y = (uint32_t)__builtin_bit_cast(unsigned short, bq[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[3]) << 16);
-            *(uint2*)dst = u;
-            if constexpr (STATS) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) v[i] = (float)bq[i];     // statistics of the values as stored
-            }
-          }
-          if constexpr (STATS) {
-            if (col_ok) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) { ssum[4 * g + i] += v[i]; ssq[4 * g + i] = fmaf(v[i], v[i], ssq[4 * g + i]); }
-            }
-          }
-        }
-#pragma unroll
-        for (int pl = 0; pl < GPL; ++pl) {
-          const int vplane = (cot * NCG + cg) * GPL + pl;
-          const int ygrp = vplane / p.y_gplanes;
-          const int yplane = vplane - ygrp * p.y_gplanes;
-          const int px = lane >> 1, pc = lane & 1;
-          const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
-#ifdef CV_ABLATE_NO_STORE
-          if (val.x == 0x12345678u)
-#endif
-          if (yplane < p.y_nplanes && wbase + px < p.W) {
-            const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
-                             (long)(wbase + px) * p.y_wmul + ygrp;
-            *(uint4*)(yb + rec * 32 + 16 * pc) = val;
-          }
-        }
-      }
-    }
-    if constexpr (STATS) {
-      // sum over the 32 pixel lanes of each half-wave (xor masks < 32 stay inside a half), lane 0 / 32 keeps the totals
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = ssum[r], b = ssq[r];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
-        if (l31 == 0) {
-          const int ch = cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-          stat_lds[(wave * COT + ch) * 2] = a;
-          stat_lds[(wave * COT + ch) * 2 + 1] = b;
-        }
-      }
-    }
-  }
+  constexpr int NPL = COT / EPR;                    // planes of the tile's channels = KiB of scratch per wave
+  float* stat_lds = (float*)(smem_all + 4 * NPL * 1024);            // [wave][COT][2], past every wave's scratch
+  conv_epilogue_store<T, HT, COT, STATS>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2, n, h0, w0 + 32 * wave,
+                                         cot, lane);
   if constexpr (STATS) {
     // BatchNorm statistics of this tile: partial[pixel tile][channel][sum, sum of squares] (bn_finalize_kernel's layout)
     __syncthreads();

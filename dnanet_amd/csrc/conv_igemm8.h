@@ -17,67 +17,7 @@
 #include <type_traits>
 #include "conv_igemm.h"
 
-// epilogue shared by the 8-wave kernels: as conv_igemm.h (bias + ReLU in registers, wave-private LDS scratch, 1-KiB stores)
-template <typename T, int HT, int COT>
-__device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_t (&acc)[HT][COT / 32], unsigned char* scratch,
-                                                    int n, int h0, int wbase, int cot, int lane) {
-  constexpr int NCG = COT / 32, EPR = RecTraits<T>::EPR, NPL = COT / EPR;
-  const int l31 = lane & 31, half = lane >> 5;
-  unsigned char* yb = (unsigned char*)p.y;
-  const int yrow = p.W * p.y_wmul;
-  // this lane's 16 bias values per channel group, fetched once (one batch of loads, one wait) instead of inside the
-  // row loop, where every row paid a load latency
-  float bias_r[NCG][16];
-#pragma unroll
-  for (int cg = 0; cg < NCG; ++cg)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      bias_r[cg][r] = p.bias ? p.bias[cot * COT + cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
-#pragma unroll
-  for (int hh = 0; hh < HT; ++hh) {
-    const int h = h0 + hh;
-    if (h < p.H) {                                  // block-uniform
-#pragma unroll
-      for (int cg = 0; cg < NCG; ++cg) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = cg * 32 + 8 * g + 4 * half;
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[i] = acc[hh][cg][4 * g + i] + bias_r[cg][4 * g + i];
-            if (p.relu) v[i] = fmaxf(v[i], 0.f);
-          }
-          unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
-          if constexpr (sizeof(T) == 4) {
-            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            __bf16 b0 = (__bf16)v[0], b1 = (__bf16)v[1], b2 = (__bf16)v[2], b3 = (__bf16)v[3];
-            uint2 u;
-            u.x = (uint32_t)__builtin_bit_cast(unsigned short, b0) | ((uint32_t)__builtin_bit_cast(unsigned short, b1) << 16);
-            u.y = (uint32_t)__builtin_bit_cast(unsigned short, b2) | ((uint32_t)__builtin_bit_cast(unsigned short, b3) << 16);
-            *(uint2*)dst = u;
-          }
-        }
-      }
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        const int vplane = cot * NPL + pl;
-        const int ygrp = vplane / p.y_gplanes;
-        const int yplane = vplane - ygrp * p.y_gplanes;
-        const int px = lane >> 1, pc = lane & 1;
-        const uint4 val = *(const uint4*)(scratch + pl * 1024 + lane * 16);
-        if (yplane < p.y_nplanes && wbase + px < p.W) {
-          const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
-                           (long)(wbase + px) * p.y_wmul + ygrp;
-          *(uint4*)(yb + rec * 32 + 16 * pc) = val;
-        }
-      }
-    }
-  }
-}
-
-template <typename T, int HT>
+template <typename T, int HT, bool STATS = false>
 __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p) {
   constexpr int KH = 3, KW = 5, PH = 1, PW = 2, COT = 64, NCG = 2, TW = 256;
   constexpr int ROWS = HT + KH - 1;
@@ -109,6 +49,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   const int cot = j % ncot;
   int pt = (j / ncot) * 8 + (blockIdx.x & 7);
   if (pt >= npt) return;
+  const int ptile = pt;      // index of this tile's BatchNorm partial (STATS)
   const int tw = pt % p.ntw; pt /= p.ntw;
   const int th = pt % p.nth;
   const int n = pt / p.nth;
@@ -294,7 +235,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   }
   const long long prof_t1 = clock64();
 #endif
-  conv_epilogue_store<T, HT, COT>(p, acc, smem + wave * (NPL * 1024), n, h0, w0 + 32 * wave, cot, lane);
+  float* stat_lds = (float*)(smem + 8 * NPL * 1024);                // [wave][COT][2], past every wave's scratch
+  conv_epilogue_store<T, HT, COT, STATS>(p, acc, smem + wave * (NPL * 1024), stat_lds + wave * COT * 2, n, h0, w0 + 32 * wave,
+                                         cot, lane);
 #ifdef C8_PROFILE_WAIT
   if (lane == 0 && p.dbg) {
     long long* d = p.dbg + 3L * 8 * gridDim.x + ((long)blockIdx.x * 8 + wave) * 3;
@@ -304,13 +247,23 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
     d[2] = clock64() - prof_t1;            // ... up to the last store acknowledged
   }
 #endif
+  // BatchNorm statistics of this 256-column tile: sum the 8 waves' (sum, sum of squares), fixed order
+  if constexpr (STATS) {
+    __syncthreads();
+    if (tid < COT * 2) {
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) t += stat_lds[wv * COT * 2 + tid];
+      p.stats[((long)ptile * p.cout_pad + cot * COT) * 2 + tid] = t;
+    }
+  }
 }
 
 // ---- chunk-granular variant for 3-row tiles (6-dye profiles): a kernel-column step of a 3-row tile is only ~16 MFMAs
 // per wave, too few to pay for a barrier each, and its LDS images are small enough to double buffer BOTH operands
 // (2 x 41.6 KiB activations + 2 x 30 KiB weights = 143 KiB).  One barrier per K chunk; the whole next chunk streams
 // in while the current one (84-90 MFMAs per wave) is consumed.
-template <typename T, int HT>
+template <typename T, int HT, bool STATS = false>
 __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p) {
   constexpr int KH = 3, KW = 5, TAPS = 15, PH = 1, PW = 2, COT = 64, NCG = 2, TW = 256;
   constexpr int ROWS = HT + KH - 1;
@@ -335,6 +288,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p
   const int cot = j % ncot;
   int pt = (j / ncot) * 8 + (blockIdx.x & 7);
   if (pt >= npt) return;
+  const int ptile = pt;      // index of this tile's BatchNorm partial (STATS)
   const int tw = pt % p.ntw; pt /= p.ntw;
   const int th = pt % p.nth;
   const int n = pt / p.nth;
@@ -436,7 +390,19 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p
   constexpr int NPL = COT / EPR;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  conv_epilogue_store<T, HT, COT>(p, acc, smem_all + wave * (NPL * 1024), n, h0, w0 + 32 * wave, cot, lane);
+  float* stat_lds = (float*)(smem_all + 8 * NPL * 1024);            // [wave][COT][2], past every wave's scratch
+  conv_epilogue_store<T, HT, COT, STATS>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2, n, h0, w0 + 32 * wave,
+                                         cot, lane);
+  // BatchNorm statistics of this 256-column tile: sum the 8 waves' (sum, sum of squares), fixed order
+  if constexpr (STATS) {
+    __syncthreads();
+    if (tid < COT * 2) {
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) t += stat_lds[wv * COT * 2 + tid];
+      p.stats[((long)ptile * p.cout_pad + cot * COT) * 2 + tid] = t;
+    }
+  }
 }
 
 // the 8-wave kernel pays off once a block has enough K chunks to pipeline and the row holds whole 256-column tiles
@@ -444,15 +410,15 @@ inline bool conv_igemm8_applies(const ConvParams& p, int kh, int kw) {
   return kh == 3 && kw == 5 && p.cout_pad % 64 == 0 && p.W % 256 == 0 && p.nchunk >= 4 && p.x_wmul == 1 && p.y_wmul == 1;
 }
 
-template <typename T, int HT, bool CHUNKED = false>
+template <typename T, int HT, bool CHUNKED = false, bool STATS = false>
 int conv_igemm8_launch(ConvParams p, hipStream_t stream) {
   p.ntw = p.W / 256;
   p.nth = (p.H + HT - 1) / HT;
   const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / 64);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
-  if constexpr (CHUNKED) hipLaunchKernelGGL((conv_igemm8c_kernel<T, HT>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((conv_igemm8_kernel<T, HT>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+  if constexpr (CHUNKED) hipLaunchKernelGGL((conv_igemm8c_kernel<T, HT, STATS>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm8_kernel<T, HT, STATS>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

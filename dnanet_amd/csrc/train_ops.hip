@@ -103,11 +103,27 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned ch
 __global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                    float* mean_out, float* invstd_out, float* scale, float* shift) {
-  const int c = blockIdx.x;       // one wave per channel
+  const int c = blockIdx.x;       // one 256-thread block per channel
   if (c >= C) { if (threadIdx.x == 0) { scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
-  const double s = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2);
-  const double ss = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2 + 1);
+  // With the statistics fused into the convolution there is one partial per conv tile (thousands): every thread keeps
+  // four (sum, sum of squares) pairs in flight, fixed order, fp64 accumulation.
+  const float2* p = (const float2*)partial + c;
+  double s = 0.0, ss = 0.0;
+  int i = threadIdx.x;
+  for (; i + 768 < nblk; i += 1024) {
+    const float2 a = p[(long)i * cpad], b = p[(long)(i + 256) * cpad], d = p[(long)(i + 512) * cpad], e = p[(long)(i + 768) * cpad];
+    s += ((double)a.x + (double)b.x) + ((double)d.x + (double)e.x);
+    ss += ((double)a.y + (double)b.y) + ((double)d.y + (double)e.y);
+  }
+  for (; i < nblk; i += 256) { const float2 a = p[(long)i * cpad]; s += a.x; ss += a.y; }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); ss += __shfl_xor(ss, m); }
+  __shared__ double red[4][2];
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = ss; }
+  __syncthreads();
   if (threadIdx.x != 0) return;
+  s = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  ss = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
   const double mean = s / count;
   double var = ss / count - mean * mean;
   if (var < 0) var = 0;
@@ -533,7 +549,7 @@ static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, 
     "dn_bn_train_forward");
   }
   DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(256), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   DN_LAUNCH_CHECK();
   const int npieces = (int)(HW * 2);

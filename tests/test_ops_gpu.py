@@ -143,7 +143,8 @@ def test_conv2d(gpu_device, case, dtype, ints):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 32, 32, 5, 64, 3, 5), (3, 16, 24, 6, 200, 3, 5), (2, 64, 72, 5, 300, 3, 5),
-                                  (1, 32, 128, 3, 128, 3, 5), (2, 16, 40, 5, 130, 1, 3), (130, 32, 32, 5, 512, 3, 5)])
+                                  (1, 32, 128, 3, 128, 3, 5), (2, 16, 40, 5, 130, 1, 3), (130, 32, 32, 5, 512, 3, 5),
+                                  (8, 64, 512, 5, 2048, 3, 5), (8, 64, 512, 6, 2048, 3, 5)])   # the last two: 8-wave kernels
 def test_conv2d_stats(gpu_device, case, dtype):
     """dn_conv2d_stats: same y as dn_conv2d without ReLU, and per-tile (sum, sum of squares) of the *stored* values
     whose totals equal a separate pass over y (integer data: exact)."""
@@ -155,6 +156,9 @@ def test_conv2d_stats(gpu_device, case, dtype):
     wt = torch.randint(-1, 2, (cout, cin, kh, kw), generator=g).float()
     b = torch.randint(-3, 4, (cout,), generator=g).float()
     ref = F.conv2d(x, wt, b, padding=(kh // 2, kw // 2))
+    if cin == 64 and cout == 512:
+        tag = _variant(hip, cin, cout, n, h, w, kh, kw, dtype)
+        assert tag.startswith("conv_igemm8") == (h == 5 or dtype == 0), tag
     xb = hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype)
     packed = _pack(hip, wt, None, hip.PACK_FWD, dtype, gpu_device)
     cp = hip.channel_pad(cout)
