@@ -91,7 +91,20 @@ int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, in
 }
 
 static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
-                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream);
+                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream,
+                       const dn_tensor* pooled = nullptr);
+
+int dn_conv2d_pool(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, dn_tensor pooled, int N, int H, int W,
+                   int kh, int kw, int relu, int dtype, void* stream) {
+  DN_CHECK_ARG(pooled.base, "dn_conv2d_pool: null pointer");
+  DN_CHECK_ARG((kh == 3 && kw == 5) || (kh == 1 && kw == 3), "dn_conv2d_pool: kernel size (%d,%d) has no pooling epilogue", kh, kw);
+  DN_CHECK_ARG(W % 2 == 0 && pooled.channels == y.channels, "dn_conv2d_pool: W=%d must be even and pooled.channels=%d == y.channels=%d",
+               W, pooled.channels, y.channels);
+  const int pp = dn_planes(pooled.channels, dtype);
+  DN_CHECK_ARG(pooled.plane0 >= 0 && pooled.plane0 + pp <= pooled.planes_total, "dn_conv2d_pool: pooled planes [%d,%d) outside buffer of %d",
+               pooled.plane0, pooled.plane0 + pp, pooled.planes_total);
+  return conv2d_impl(x, packed_w, bias, y, N, H, W, kh, kw, relu, dtype, nullptr, 0, nullptr, stream, &pooled);
+}
 
 int dn_conv2d_stats(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
                     int dtype, float* partial, long partial_floats, int* ntiles, void* stream) {
@@ -144,7 +157,7 @@ int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx
 }  // extern "C"
 
 static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
-                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream) {
+                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream, const dn_tensor* pooled) {
   DN_CHECK_ARG(x.base && packed_w && y.base, "dn_conv2d: null pointer");
   DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && x.channels > 0 && y.channels > 0, "dn_conv2d: bad shape N=%d H=%d W=%d", N, H, W);
   DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d: bad dtype %d", dtype);
@@ -158,6 +171,7 @@ static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_
   p.w = packed_w; p.bias = bias;
   p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
   p.N = N; p.H = H; p.W = W; p.nchunk = xp; p.cout_pad = dn_channel_pad(y.channels); p.relu = relu;
+  if (pooled) { p.pool = pooled->base; p.pool_planes_total = pooled->planes_total; p.pool_plane0 = pooled->plane0; }
   if (stats) {
     p.stats = stats;
     const ConvVariant v = choose_variant(p, kh, kw, dtype);

@@ -29,7 +29,8 @@ struct ConvParams {
   int cout_pad;             // multiple of COT
   int relu;
   int ntw, nth;             // column / row tiles per image
-  float* stats;             // BatchNorm partial sums [pixel tile][cout_pad][2] (STATS instantiations), else unused
+  float* stats;             // BatchNorm partial sums [pixel tile][cout_pad][2] (CONV_EPI_STATS instantiations), else unused
+  void* pool; int pool_planes_total, pool_plane0;   // MaxPool2d((1,2)) of y, W/2 columns (CONV_EPI_POOL), else unused
 #ifdef C8_PROFILE_WAIT
   long long* dbg;           // [waves][3]: cycles in vmcnt waits, in barriers, total (scratch/conv8_micro.hip)
 #endif
@@ -52,6 +53,11 @@ template <> struct Mma32<float> {
   }
 };
 
+// What the epilogue does besides storing y
+constexpr int CONV_EPI_PLAIN = 0;   // nothing
+constexpr int CONV_EPI_STATS = 1;   // + BatchNorm batch statistics of y (training forward)
+constexpr int CONV_EPI_POOL = 2;    // + MaxPool2d((1,2)) of y into a second buffer (encoder blocks, eval mode)
+
 // Epilogue shared by the 4-wave and 8-wave kernels: bias (+ folded BN) + ReLU in registers, then through a wave-private
 // LDS scratch so that every global store instruction writes 1 KiB of consecutive 16-byte pieces (32 pixels of one
 // plane row) instead of 8-byte fragments at a 32-byte stride.  A lane's bias values are fetched once, before the rows.
@@ -59,9 +65,14 @@ template <> struct Mma32<float> {
 // STATS form: one pass per 32-channel group, so that a lane holds only 16 running (sum, sum of squares) pairs of the
 // values AS STORED (bf16-rounded) -- BatchNorm's batch statistics; they end up in stat_wave[channel of the tile][2]
 // (LDS, this wave's).
-template <typename T, int HT, int COT, bool STATS>
+// POOL form: the plain form, plus max over each even/odd column pair (neighbouring lanes; rounding is monotonic, so the
+// max of the fp32 values rounds to the max of the stored ones) through a second scratch (COT/EPR x 512 B per wave) into
+// p.pool -- unet_architecture.py:37 without a second pass over the skip tensor.
+template <typename T, int HT, int COT, int EPI>
 __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_t (&acc)[HT][COT / 32], unsigned char* scratch,
-                                                    float* stat_wave, int n, int h0, int wbase, int cot, int lane) {
+                                                    float* stat_wave, unsigned char* pool_scratch, int n, int h0, int wbase,
+                                                    int cot, int lane) {
+  constexpr bool STATS = EPI == CONV_EPI_STATS, POOL = EPI == CONV_EPI_POOL;
   constexpr int NCG = COT / 32, EPR = RecTraits<T>::EPR, GPL = 32 / EPR;
   constexpr int NPASS = STATS ? NCG : 1, CPP = NCG / NPASS;        // passes over the rows, channel groups per pass
   const int l31 = lane & 31, half = lane >> 5;
@@ -112,6 +123,23 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
                 for (int i = 0; i < 4; ++i) { ssum[4 * g + i] += v[i]; ssq[4 * g + i] = fmaf(v[i], v[i], ssq[4 * g + i]); }
               }
             }
+            if constexpr (POOL) {
+              float m[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) m[i] = fmaxf(v[i], __shfl_xor(v[i], 1));
+              if ((l31 & 1) == 0) {
+                unsigned char* pd = pool_scratch + (cl / EPR) * 512 + (l31 >> 1) * 32 + (cl % EPR) * sizeof(T);
+                if constexpr (sizeof(T) == 4) {
+                  *(float4*)pd = make_float4(m[0], m[1], m[2], m[3]);
+                } else {
+                  __bf16 bq[4] = {(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+                  uint2 u;
+                  u.x = (uint32_t)__builtin_bit_cast(unsigned short, bq[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[1]) << 16);
+                  u.y = (uint32_t)__builtin_bit_cast(unsigned short, bq[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[3]) << 16);
+                  *(uint2*)pd = u;
+                }
+              }
+            }
           }
         }
 #pragma unroll
@@ -128,6 +156,19 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
             const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
                              (long)(wbase + px) * p.y_wmul + ygrp;
             *(uint4*)(yb + rec * 32 + 16 * pc) = val;
+          }
+        }
+        if constexpr (POOL) {
+          // 16 pooled pixels x 32 B per plane: the lower half-wave stores 512 consecutive bytes per plane
+          const int wp = p.W >> 1, px = (lane & 31) >> 1, pc = lane & 1;
+#pragma unroll
+          for (int pl = 0; pl < CPP * GPL; ++pl) {
+            const int yplane = (cot * NCG + ps * CPP) * GPL + pl;
+            const uint4 val = *(const uint4*)(pool_scratch + pl * 512 + (lane & 31) * 16);
+            if (lane < 32 && yplane < p.y_nplanes && (wbase >> 1) + px < wp) {
+              const long rec = ((long)(n * p.pool_planes_total + p.pool_plane0 + yplane) * p.H + h) * wp + (wbase >> 1) + px;
+              *(uint4*)((unsigned char*)p.pool + rec * 32 + 16 * pc) = val;
+            }
           }
         }
       }
@@ -154,8 +195,9 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
 // with both.  The choice is per block, so the chunk loop exists in four compile-time variants and each block runs
 // one; inside a variant the MFMA loop has no branches, so the fragment reads and MFMAs of a whole chunk are
 // scheduled as one basic block.
-template <typename T, int KH, int KW, int HT, int COT, bool STATS = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+template <typename T, int KH, int KW, int HT, int COT, int EPI = CONV_EPI_PLAIN, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams p) {
+  constexpr bool STATS = EPI == CONV_EPI_STATS;
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
   constexpr int ROWS = HT + KH - 1;
   constexpr int QW = 128 + KW - 1;
@@ -165,12 +207,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   constexpr int ACT_BYTES = (ACT_RAW + 1023) / 1024 * 1024;          // weight image starts on a 1-KiB piece boundary
   constexpr int W_BYTES = TAPS * COT * 32;
   constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 4095) / 4096;      // wave-instructions of 1 KiB per wave
-  constexpr int EPI_BYTES = 4 * (COT / EPR) * 1024 + 4 * COT * 2 * 4;  // epilogue: 4 waves x COT channels + statistics
+  constexpr int EPI_BYTES = 4 * (COT / EPR) * 1536 + 4 * COT * 2 * 4;  // epilogue: 4 waves x COT channels (+ pooled) + statistics
   constexpr int BUF_BYTES = ST_ITERS * 4096;
   // K chunks are software pipelined through NBUF LDS images when two workgroups of them fit a CU (1x1 / 1x3 kernels:
   // a chunk is only HT*NCG MFMAs per wave, far less than a load latency); the 3x5 images are too big for that and
   // rely on the CU's other workgroup to cover their load phase.
-  constexpr int NBUF = 2 * 3 * BUF_BYTES <= 160 * 1024 ? 3 : (2 * 2 * BUF_BYTES <= 160 * 1024 ? 2 : 1);
+  // MINB = 1 (one workgroup per CU, 512 registers per lane: the 6-row x 64-channel tile) has nobody else to cover its
+  // loads, and room for two images of its own.
+  constexpr int NBUF = MINB * 3 * BUF_BYTES <= 160 * 1024 ? 3 : (MINB * 2 * BUF_BYTES <= 160 * 1024 ? 2 : 1);
   static_assert((NBUF - 1) * ST_ITERS < 64, "vmcnt is a 6-bit counter");
   constexpr int SMEM_BYTES = NBUF * BUF_BYTES > EPI_BYTES ? NBUF * BUF_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem_all[SMEM_BYTES];
@@ -341,8 +385,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   __syncthreads();                                  // all waves are done reading the staged tiles
   constexpr int NPL = COT / EPR;                    // planes of the tile's channels = KiB of scratch per wave
   float* stat_lds = (float*)(smem_all + 4 * NPL * 1024);            // [wave][COT][2], past every wave's scratch
-  conv_epilogue_store<T, HT, COT, STATS>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2, n, h0, w0 + 32 * wave,
-                                         cot, lane);
+  unsigned char* pool_lds = smem_all + 4 * NPL * 1024 + 4 * COT * 2 * 4;   // [wave][NPL][512 B]
+  conv_epilogue_store<T, HT, COT, EPI>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
+                                       pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
   if constexpr (STATS) {
     // BatchNorm statistics of this tile: partial[pixel tile][channel][sum, sum of squares] (bn_finalize_kernel's layout)
     __syncthreads();
@@ -355,15 +400,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   }
 }
 
-template <typename T, int KH, int KW, int HT, int COT, bool STATS = false>
+template <typename T, int KH, int KW, int HT, int COT, int EPI = CONV_EPI_PLAIN, int MINB = 2>
 int conv_igemm_launch(ConvParams p, hipStream_t stream) {
   p.ntw = (p.W + 127) / 128;
   p.nth = (p.H + HT - 1) / HT;
   const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / COT);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * p.x_wmul * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
-  if constexpr (STATS) hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, EPI, MINB>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

@@ -17,8 +17,9 @@
 #include <type_traits>
 #include "conv_igemm.h"
 
-template <typename T, int HT, bool STATS = false>
+template <typename T, int HT, int EPI = CONV_EPI_PLAIN>
 __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p) {
+  constexpr bool STATS = EPI == CONV_EPI_STATS;
   constexpr int KH = 3, KW = 5, PH = 1, PW = 2, COT = 64, NCG = 2, TW = 256;
   constexpr int ROWS = HT + KH - 1;
   constexpr int QW = TW + KW - 1;
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   constexpr int W_OFF = 2 * ACT_BUF, SCRAP_OFF = W_OFF + KW * W_SLICE;
   constexpr int SMEM_BYTES = SCRAP_OFF + 1024;
   static_assert(W_SLICE == 6 * 1024 && SMEM_BYTES <= 160 * 1024, "LDS plan");
+  static_assert(8 * (COT / EPR) * 1536 + 8 * COT * 8 <= SMEM_BYTES, "epilogue scratch (stores, pooled, statistics) fits the tile buffers");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
   const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
@@ -236,8 +238,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   const long long prof_t1 = clock64();
 #endif
   float* stat_lds = (float*)(smem + 8 * NPL * 1024);                // [wave][COT][2], past every wave's scratch
-  conv_epilogue_store<T, HT, COT, STATS>(p, acc, smem + wave * (NPL * 1024), stat_lds + wave * COT * 2, n, h0, w0 + 32 * wave,
-                                         cot, lane);
+  unsigned char* pool_lds = smem + 8 * NPL * 1024 + 8 * COT * 2 * 4;   // [wave][NPL][512 B]
+  conv_epilogue_store<T, HT, COT, EPI>(p, acc, smem + wave * (NPL * 1024), stat_lds + wave * COT * 2,
+                                       pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
 #ifdef C8_PROFILE_WAIT
   if (lane == 0 && p.dbg) {
     long long* d = p.dbg + 3L * 8 * gridDim.x + ((long)blockIdx.x * 8 + wave) * 3;
@@ -263,8 +266,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
 // per wave, too few to pay for a barrier each, and its LDS images are small enough to double buffer BOTH operands
 // (2 x 41.6 KiB activations + 2 x 30 KiB weights = 143 KiB).  One barrier per K chunk; the whole next chunk streams
 // in while the current one (84-90 MFMAs per wave) is consumed.
-template <typename T, int HT, bool STATS = false>
+template <typename T, int HT, int EPI = CONV_EPI_PLAIN>
 __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p) {
+  constexpr bool STATS = EPI == CONV_EPI_STATS;
   constexpr int KH = 3, KW = 5, TAPS = 15, PH = 1, PW = 2, COT = 64, NCG = 2, TW = 256;
   constexpr int ROWS = HT + KH - 1;
   constexpr int QW = TW + KW - 1;
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p
   constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 8191) / 8192;       // 1-KiB pieces per wave (8 waves)
   constexpr int BUF_BYTES = ST_ITERS * 8192;
   static_assert(2 * BUF_BYTES <= 160 * 1024, "both operands double buffered");
+  static_assert(8 * (COT / EPR) * 1536 + 8 * COT * 8 <= 2 * BUF_BYTES, "epilogue scratch (stores, pooled, statistics) fits the tile buffers");
   __shared__ __attribute__((aligned(16))) unsigned char smem_all[2 * BUF_BYTES];
   const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all);
 
@@ -391,8 +396,9 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   float* stat_lds = (float*)(smem_all + 8 * NPL * 1024);            // [wave][COT][2], past every wave's scratch
-  conv_epilogue_store<T, HT, COT, STATS>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2, n, h0, w0 + 32 * wave,
-                                         cot, lane);
+  unsigned char* pool_lds = smem_all + 8 * NPL * 1024 + 8 * COT * 2 * 4;   // [wave][NPL][512 B]
+  conv_epilogue_store<T, HT, COT, EPI>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
+                                       pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
   // BatchNorm statistics of this 256-column tile: sum the 8 waves' (sum, sum of squares), fixed order
   if constexpr (STATS) {
     __syncthreads();
@@ -410,15 +416,15 @@ inline bool conv_igemm8_applies(const ConvParams& p, int kh, int kw) {
   return kh == 3 && kw == 5 && p.cout_pad % 64 == 0 && p.W % 256 == 0 && p.nchunk >= 4 && p.x_wmul == 1 && p.y_wmul == 1;
 }
 
-template <typename T, int HT, bool CHUNKED = false, bool STATS = false>
+template <typename T, int HT, bool CHUNKED = false, int EPI = CONV_EPI_PLAIN>
 int conv_igemm8_launch(ConvParams p, hipStream_t stream) {
   p.ntw = p.W / 256;
   p.nth = (p.H + HT - 1) / HT;
   const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / 64);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
-  if constexpr (CHUNKED) hipLaunchKernelGGL((conv_igemm8c_kernel<T, HT, STATS>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((conv_igemm8_kernel<T, HT, STATS>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+  if constexpr (CHUNKED) hipLaunchKernelGGL((conv_igemm8c_kernel<T, HT, EPI>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm8_kernel<T, HT, EPI>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

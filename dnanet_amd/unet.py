@@ -149,20 +149,27 @@ class HipUNet(ParameterTree):
         hip.check(hip.lib.dn_conv2d_variant(cin, cout, n, h, w, kh, kw, self.dtype, buf, len(buf)))
         return buf.value.decode()
 
-    def _conv(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1):
+    def _conv(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1, pooled=None):
+        """``pooled``: also write MaxPool2d((1,2)) of the output there (fused epilogue, ``dn_conv2d_pool``)."""
         if self.profile is not None and u.cin != 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._conv_launch(u, entry, src, dst, n, h, w, relu)
+            self._conv_launch(u, entry, src, dst, n, h, w, relu, pooled)
             e1.record()
             kh, kw = self.kernel_size
             self.profile.append((self.conv_kernel_tag(u.cin, u.cout, n, h, w), 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
         else:
-            self._conv_launch(u, entry, src, dst, n, h, w, relu)
+            self._conv_launch(u, entry, src, dst, n, h, w, relu, pooled)
 
-    def _conv_launch(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1):
+    def _conv_launch(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1, pooled=None):
         kh, kw = self.kernel_size
-        if u.cin == 1:
+        if pooled is not None and (u.cin == 1 or (kh, kw) not in ((3, 5), (1, 3))):
+            self._conv_launch(u, entry, src, dst, n, h, w, relu)
+            hip.check(hip.lib.dn_maxpool_1x2(dst, pooled, n, h, w // 2, self.dtype, hip.stream_ptr()))
+        elif pooled is not None:
+            hip.check(hip.lib.dn_conv2d_pool(src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), dst, pooled, n, h, w, kh, kw,
+                                             relu, self.dtype, hip.stream_ptr()))
+        elif u.cin == 1:
             hip.check(hip.lib.dn_conv_first(hip.ptr(src), hip.ptr(entry["wf"]), hip.ptr(entry["bias"]), dst, n, h, w,
                                             u.cout, kh, kw, relu, self.dtype, hip.stream_ptr()))
         else:
@@ -184,9 +191,8 @@ class HipUNet(ParameterTree):
             tmp = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
             self._conv(units[pre + ".0"], cache[pre + ".0"], cur if l == 0 else cur.ref(c[l - 1]), tmp.ref(c[l]), n, h, ws[l])
             skip = cat[l].ref(c[l], self._pp(c[l]))
-            self._conv(units[pre + ".3"], cache[pre + ".3"], tmp.ref(c[l]), skip, n, h, ws[l])
             pooled = PlaneBuffer(n, self._pp(c[l]), h, ws[l + 1], dt, dev)
-            hip.check(hip.lib.dn_maxpool_1x2(skip, pooled.ref(c[l]), n, h, ws[l + 1], dt, hip.stream_ptr()))
+            self._conv(units[pre + ".3"], cache[pre + ".3"], tmp.ref(c[l]), skip, n, h, ws[l], pooled=pooled.ref(c[l]))
             cur = pooled
         pre = "bottleneck.double_conv"
         tmp = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev)

@@ -115,6 +115,11 @@ int dn_reduce_blocks(long pixels);
 int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                         float* scale, float* shift, float* partial, int dtype, void* stream);
+/* dn_conv2d followed by nn.MaxPool2d((1,2)) (EncoderBlock, unet_architecture.py:28-42: returns (skip, pooled)) in one
+ * kernel: y gets the convolution output (the skip tensor), pooled[n,c,h,w] = max(y[n,c,h,2w], y[n,c,h,2w+1]) with W/2
+ * columns.  Kernel sizes (3,5) and (1,3); W even. */
+int dn_conv2d_pool(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, dn_tensor pooled, int N, int H, int W,
+                   int kh, int kw, int relu, int dtype, void* stream);
 /* The convolution of a DoubleConv in training mode (nn.Conv2d + bias feeding nn.BatchNorm2d, unet_architecture.py:14-17)
  * with the BatchNorm batch statistics taken in the convolution's epilogue: y as dn_conv2d(relu = 0), and per pixel tile
  * and channel the sum and sum of squares of the values as stored, partial[tile][dn_channel_pad(cout)][2]

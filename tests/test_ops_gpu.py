@@ -145,6 +145,42 @@ def test_conv2d(gpu_device, case, dtype, ints):
 @pytest.mark.parametrize("case", [(2, 32, 32, 5, 64, 3, 5), (3, 16, 24, 6, 200, 3, 5), (2, 64, 72, 5, 300, 3, 5),
                                   (1, 32, 128, 3, 128, 3, 5), (2, 16, 40, 5, 130, 1, 3), (130, 32, 32, 5, 512, 3, 5),
                                   (8, 64, 512, 5, 2048, 3, 5), (8, 64, 512, 6, 2048, 3, 5)])   # the last two: 8-wave kernels
+def test_conv2d_pool(gpu_device, case, dtype):
+    """dn_conv2d_pool: y as dn_conv2d writes it, plus MaxPool2d((1,2)) of y in a second buffer (integer data: exact);
+    planes next to both outputs stay untouched."""
+    hip = _hip()
+    n, cin, cout, h, w, kh, kw = case
+    g = torch.Generator().manual_seed(23 + dtype)
+    x = torch.randint(-2, 3, (n, cin, h, w), generator=g).float()
+    wt = torch.randint(-1, 2, (cout, cin, kh, kw), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    ref = F.conv2d(x, wt, b, padding=(kh // 2, kw // 2)).relu()
+    xb = hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype)
+    packed = _pack(hip, wt, None, hip.PACK_FWD, dtype, gpu_device)
+    bias = _padvec(b, hip.channel_pad(cout), gpu_device)
+    pl = hip.planes(cout, dtype)
+    yb = hip.PlaneBuffer(n, pl + 2, h, w, dtype, gpu_device, zero=True)
+    pb = hip.PlaneBuffer(n, pl + 2, h, w // 2, dtype, gpu_device, zero=True)
+    hip.check(hip.lib.dn_conv2d_pool(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), yb.ref(cout, 1), pb.ref(cout, 1), n, h, w,
+                                     kh, kw, 1, dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    want = _q(ref, dtype)
+    assert torch.equal(yb.to_nchw(cout, 1).cpu(), want)
+    assert torch.equal(pb.to_nchw(cout, 1).cpu(), F.max_pool2d(want, (1, 2)))
+    for buf in (yb, pb):
+        assert float(buf.data[:, :1].abs().max()) == 0 and float(buf.data[:, -1:].abs().max()) == 0
+    e = hip.epr(dtype)
+    if cout % e:
+        assert float(pb.data[:, 1 + cout // e, :, :, cout % e:].abs().max()) == 0
+    # odd width is refused
+    assert hip.lib.dn_conv2d_pool(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), yb.ref(cout, 1), pb.ref(cout, 1), n, h, w - 1,
+                                  kh, kw, 1, dtype, hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(2, 32, 32, 5, 64, 3, 5), (3, 16, 24, 6, 200, 3, 5), (2, 64, 72, 5, 300, 3, 5),
+                                  (1, 32, 128, 3, 128, 3, 5), (2, 16, 40, 5, 130, 1, 3), (130, 32, 32, 5, 512, 3, 5),
+                                  (8, 64, 512, 5, 2048, 3, 5), (8, 64, 512, 6, 2048, 3, 5)])   # the last two: 8-wave kernels
 def test_conv2d_stats(gpu_device, case, dtype):
     """dn_conv2d_stats: same y as dn_conv2d without ReLU, and per-tile (sum, sum of squares) of the *stored* values
     whose totals equal a separate pass over y (integer data: exact)."""
