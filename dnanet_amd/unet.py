@@ -157,7 +157,8 @@ class HipUNet(ParameterTree):
             self._conv_launch(u, entry, src, dst, n, h, w, relu, pooled)
             e1.record()
             kh, kw = self.kernel_size
-            self.profile.append((self.conv_kernel_tag(u.cin, u.cout, n, h, w), 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
+            tag = self.conv_kernel_tag(u.cin, u.cout, n, h, w) + ("+pool" if pooled is not None else "")
+            self.profile.append((tag, 2.0 * n * h * w * u.cout * u.cin * kh * kw, e0, e1))
         else:
             self._conv_launch(u, entry, src, dst, n, h, w, relu, pooled)
 

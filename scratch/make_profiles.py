@@ -1,0 +1,52 @@
+"""Turn the rocprofv3 output of scratch/profile_bench.sh (under gpurun_out/) into the committed files of profiles/.
+
+    python scratch/make_profiles.py [round tag, default r01]
+
+The dominant kernel is the one with the largest total duration in the inference-only kernel-stats pass; FETCH_SIZE /
+WRITE_SIZE are summed per kernel name from the two counter passes (KiB, raw) and combined as 2 x FETCH + WRITE
+(MI355X_MICROARCH.md: gfx950 tallies 128-B read requests at 64 B)."""
+import csv, json, os, shutil, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+def bench_line(log):
+    lines = [l for l in open(os.path.join(G, log)) if l.startswith('{"metric"')]
+    return json.loads(lines[-1])
+
+shutil.copy(os.path.join(G, "prof_infer", "p_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_bf16_h6_infer_kernel_stats.csv"))
+shutil.copy(os.path.join(G, "prof_full", "p_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_bf16_h6_kernel_stats.csv"))
+infer_line, full_line = bench_line("prof_infer_bench.log"), bench_line("prof_full_bench.log")
+json.dump(infer_line, open(os.path.join(P, f"{tag}_bench_bf16_h6_infer_benchline.json"), "w"))
+json.dump(full_line, open(os.path.join(P, f"{tag}_bench_bf16_h6_benchline.json"), "w"))
+
+stats = list(csv.DictReader(open(os.path.join(G, "prof_infer", "p_kernel_stats.csv"))))
+dominant = max(stats, key=lambda r: float(r["TotalDurationNs"]))
+name = dominant["Name"]
+
+def per_kernel(counter, d):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(os.path.join(G, d, "p_counter_collection.csv"))):
+        if r["Counter_Name"] == counter:
+            tot[r["Kernel_Name"]] += float(r["Counter_Value"]); cnt[r["Kernel_Name"]] += 1
+    rows = sorted(tot, key=lambda k: -tot[k])[:20]
+    with open(os.path.join(P, f"{tag}_pmc_{counter.lower()}_per_kernel.csv"), "w") as f:
+        f.write(f"kernel,launches,{counter}_total_KiB,{counter}_per_launch_KiB\n")
+        for k in rows:
+            f.write(f'"{k}",{cnt[k]},{tot[k]:.0f},{tot[k] / cnt[k]:.1f}\n')
+    return tot[name] / max(cnt[name], 1) * 1024.0
+
+fetch, write = per_kernel("FETCH_SIZE", "pmc_fetch"), per_kernel("WRITE_SIZE", "pmc_write")
+rec = {"kernel": infer_line["roofline"]["kernel"], "rocprof_kernel_name": name,
+       "rocprof_avg_launch_us": float(dominant["AverageNs"]) / 1e3, "bench_avg_launch_us": infer_line["roofline"]["avg_launch_us"],
+       "fetch_size_bytes_per_launch_raw": fetch, "fetch_size_bytes_per_launch_corrected": 2 * fetch,
+       "write_size_bytes_per_launch": write, "traffic_bytes_per_launch": 2 * fetch + write,
+       "note": "separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+               "--no-train`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); averages over "
+               "the launches of the dominant kernel"}
+json.dump(rec, open(os.path.join(P, f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps(rec, indent=1))
+print("inference:", infer_line["value"], "profiles/s; roofline", infer_line["roofline"])
+print("train_step:", full_line.get("train_step"))
