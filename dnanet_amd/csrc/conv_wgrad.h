@@ -19,6 +19,7 @@
 // (bitwise reproducible; no float atomics) and scatters into the canonical parameter layout.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 struct WgradParams {
@@ -28,6 +29,7 @@ struct WgradParams {
   int N, H, W;
   int co_pad, ci_pad;
   int nsplit, nstrips, ntw, nth;
+  int skip_halo;            // leave out the products with zero halo rows (set by the launcher; tuning switch)
 };
 
 template <typename T> struct WgTraits;
@@ -102,14 +104,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 
   // this wave's taps as byte offsets into an A plane image.  A wave with fewer real taps than WT (3x5: wave 3) repeats
   // its last one into an accumulator that is never stored, which keeps the MFMA loop free of branches.
+  // 3x5: accumulator i < 3 of wave w is tap (kernel row i, column w) -- the kernel row of an accumulator is a compile-time
+  // constant, which lets the products with a zero halo row be left out below -- and accumulator 3 is column 4 of kernel
+  // row w (waves 0..2; wave 3 has none).
+  static_assert(KSPLIT || (KH == 3 && KW == 5 && WT == 4), "tap-to-wave map is written for 3x5");
+  const bool rowmap = p.skip_halo != 2;     // (tuning: 2 = the interleaved map tap = wave + 4 i)
+  auto tap_of = [&](int i) {
+    return KSPLIT ? i : !rowmap ? min(wave + 4 * i, TAPS - 1) : (i < KH ? i * KW + wave : min(wave, KH - 1) * KW + KW - 1);
+  };
   int tap_off[WT];
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
-    const int tap = KSPLIT ? i : min(wave + 4 * i, TAPS - 1);
+    const int tap = tap_of(i);
     const int dh = tap / KW, dw = tap - dh * KW;
     tap_off[i] = __builtin_amdgcn_readfirstlane((dh * QW + dw) * 32);
   }
-  const bool last_tap_real = KSPLIT || wave + 4 * (WT - 1) < TAPS;   // wave-uniform
+  const bool last_tap_real = KSPLIT || wave < KH;                   // wave-uniform (same waves under either map)
   (void)last_tap_real;
   // bf16 fragment addressing (ds_read_b64_tr_b16): 16-lane group g reads pixels 8*(g>>1).. of plane (g&1)
   const int gpl_c = (lane >> 4) & 1;
@@ -160,9 +170,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   struct StageCtx { dn_srd_t srd_dy, srd_a; unsigned so_dy, so_a, lds0; int h0, w0; };
   auto stage_begin = [&](int strip, int buf) {
     StageCtx c;
-    const int tw = strip % p.ntw;
-    const int n = strip / (p.ntw * p.nth);
-    c.h0 = (strip / p.ntw) % p.nth * HT;
+    // the row tile is the fast index: with nsplit a multiple of nth, all strips of a block (split + k * nsplit) sit at
+    // the same height in the image, so "my strips touch the top / bottom border" is a per-block constant
+    const int th = strip % p.nth, rest = strip / p.nth;
+    const int tw = rest % p.ntw;
+    const int n = rest / p.ntw;
+    c.h0 = th * HT;
     c.w0 = tw * SW;
     c.srd_dy = dn_make_srd(dyb + (long)(n * p.dy_pt + p.dy_p0) * p.H * dy_row * 32);
     c.srd_a = dn_make_srd(ab + (long)(n * p.a_pt + p.a_p0) * p.H * p.W * 32);
@@ -199,6 +212,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   for (int i = 0; i < NBUF - 1; ++i)
     stage(split + i * p.nsplit, i);
 #endif
+  // A strip at the top (bottom) of the image pairs its first (last) row with a zero halo row of A for kernel row 0
+  // (KH-1): those products are left out at compile time for accumulators 0..2 (12 of the 15 taps) -- 11 % of the MFMAs
+  // of a 5-row image.  Chosen once per block (the variants live outside the strip loop, inside it they cost 150
+  // spilled registers): the strips of a block all sit at the same height of the image (see stage_begin).
+  auto strips = [&](auto top_c, auto bot_c) {
+  constexpr bool TOP = decltype(top_c)::value, BOT = decltype(bot_c)::value;
+  auto dead = [&](int i, int r) -> bool {       // (accumulator, strip row) sees only a zero row of A
+    if (KSPLIT || i >= KH) return false;        // accumulator 3's kernel row depends on the wave
+    return (TOP && r == 0 && i == 0) || (BOT && r == HT - 1 && i == KH - 1);
+  };
   for (int strip = split; strip < p.nstrips; strip += p.nsplit, buf = buf + 1 == NBUF ? 0 : buf + 1) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ST_ITERS) : "memory");
     __syncthreads();                                    // everyone's pieces landed; everyone left the oldest buffer
@@ -226,13 +249,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
           af[cg] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WT; ++i) {
+          if (i < KH && dead(i, r)) continue;              // compile time: nobody multiplies these
 #pragma unroll
           for (int cg = 0; cg < NCIG; ++cg) {
             const unsigned char* base = abase + cg * PLG * A_PS + tap_off[i];
             const uint2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * 32);
             bf[i][cg] = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
+        }
       };
       constexpr int PPI = (ST_ITERS + NIT - 1) / NIT;   // pieces of the next strip staged per K step
       uint4 af[2][NCOG], bf[2][WT][NCIG];
@@ -252,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
           // the repeated tap of the short wave: its fragments are read (no branch in the read stream) but the MFMAs,
           // which are what the power budget pays for, are skipped
           if (i + 1 == WT && !last_tap_real) continue;
+          if (dead(i, KSPLIT ? 0 : it / NK)) continue;
 #pragma unroll
           for (int a = 0; a < NCOG; ++a)
 #pragma unroll
@@ -281,16 +307,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             for (int cg = 0; cg < NCIG; ++cg)
               bf[i][cg] = *(const float*)(smem + DY_BYTES + (cg * PLG + fpl) * A_PS + tap_off[i] + (r * QW + px) * 32 + foff);
 #pragma unroll
-          for (int i = 0; i < WT; ++i)
+          for (int i = 0; i < WT; ++i) {
+            if (i + 1 == WT && !last_tap_real) continue;
+            if (dead(i, r)) continue;
 #pragma unroll
             for (int a = 0; a < NCOG; ++a)
 #pragma unroll
               for (int c = 0; c < NCIG; ++c)
                 acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[i][c], acc[i][a][c], 0, 0, 0);
+          }
         }
       }
     }
 #endif
+  }
+  };
+  {
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    const bool fixed_height = p.skip_halo == 1 && p.nsplit % p.nth == 0;
+    const int th = split % p.nth;
+    const bool top = fixed_height && th == 0, bot = fixed_height && th == p.nth - 1;   // block-uniform
+    if constexpr (KH == 1) strips(no{}, no{});
+    else if (top && bot) strips(yes{}, yes{});
+    else if (top) strips(yes{}, no{});
+    else if (bot) strips(no{}, yes{});
+    else strips(no{}, no{});
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
@@ -299,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   float* slab = p.slab + (long)slab_idx * TAPS * p.co_pad * p.ci_pad;
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
-    const int tap = KSPLIT ? i : wave + 4 * i;
-    if (tap < TAPS) {
+    const int tap = tap_of(i);
+    if (i + 1 < WT || last_tap_real) {
 #pragma unroll
       for (int a = 0; a < NCOG; ++a)
 #pragma unroll
@@ -337,8 +379,11 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   // >= 2048 pixels per block: every slab costs a round trip through HBM
   nsplit = std::min<long>(nsplit, std::max<long>(1, (long)p.nstrips * HT * SW / 2048));
   nsplit = std::min<long>(nsplit, slab_bytes / per_slab);
+  if (nsplit >= p.nth) nsplit -= nsplit % p.nth;   // blocks of one height in the image (halo-row skipping)
   if (nsplit < 1) return dn_set_error(DN_ERR_ARG, "conv_wgrad: workspace of %ld bytes is smaller than one partial slab (%ld)",
                                       slab_bytes, per_slab);
+  static const char* noskip = getenv("DN_TUNE_WGRAD_NOSKIP");   // tuning aid
+  p.skip_halo = noskip ? atoi(noskip) == 2 ? 2 : 0 : 1;
   p.nsplit = (int)nsplit;
   *nslab_out = (int)nsplit * (KSPLIT ? 4 : 1);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, HT>), dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, p);

@@ -323,7 +323,10 @@ def test_maxpool_and_head(gpu_device, dtype):
 
 
 WGRAD_CASES = [(1, 8, 8, 1, 16, 1, 1), (1, 8, 8, 5, 64, 3, 5), (2, 32, 32, 5, 256, 3, 5), (2, 64, 128, 6, 200, 3, 5),
-               (2, 16, 24, 5, 130, 1, 3), (3, 40, 72, 7, 96, 3, 5)]
+               (2, 16, 24, 5, 130, 1, 3), (3, 40, 72, 7, 96, 3, 5),
+               # large enough for a split-K count that is a multiple of the row tiles: blocks of one image height, which
+               # leave out the products with the zero halo row (3-, 5- and 1-row strips, two / two / seven tiles high)
+               (16, 32, 64, 6, 512, 3, 5), (16, 32, 64, 10, 256, 3, 5), (8, 32, 64, 7, 512, 3, 5), (16, 32, 64, 5, 512, 3, 5)]
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
