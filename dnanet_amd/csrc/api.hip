@@ -35,6 +35,7 @@ static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype
   // faster on the 4-wave kernel at every level
   static const char* ht3_8 = getenv("DN_TUNE_CONV8_HT3");      // tuning aid: 8-wave kernel for bf16 3-row tiles too
   v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && (v.ht == 5 || ht3_8)));
+  if (p.head_w) v.wave8 = false;     // the fused head lives in the 4-wave kernel's epilogue
   static const char* stats4 = getenv("DN_TUNE_STATS_4WAVE");   // tuning aid: fused-statistics convolutions on the 4-wave kernel
   if (p.stats && stats4) v.wave8 = false;
   // Small batches (train.py's 16 profiles): the wide tiles leave CUs idle -- every 8-wave launch of the shipped net
@@ -93,6 +94,42 @@ int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, in
 static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
                        int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream,
                        const dn_tensor* pooled = nullptr);
+
+// The fused head needs the whole channel dimension of a pixel in one block: the tile the dispatcher picks for this
+// shape must be as wide as the padded channel count.
+static bool head_fits(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype) {
+  if (!((kh == 3 && kw == 5) || (kh == 1 && kw == 3)) || cin <= 1 || cout <= 0 || N <= 0 || H <= 0 || W <= 0) return false;
+  if (dtype != DN_BF16 && dtype != DN_F32) return false;
+  ConvParams p{};
+  static const float one = 1.f;
+  p.N = N; p.H = H; p.W = W; p.nchunk = dn_planes(cin, dtype); p.cout_pad = dn_channel_pad(cout); p.x_wmul = 1; p.y_wmul = 1;
+  p.head_w = &one;
+  const ConvVariant v = choose_variant(p, kh, kw, dtype);
+  return !v.wave8 && v.cot == p.cout_pad;
+}
+
+int dn_conv2d_head_supported(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype) {
+  return head_fits(cin, cout, N, H, W, kh, kw, dtype) ? 1 : 0;
+}
+
+int dn_conv2d_head(dn_tensor x, const void* packed_w, const float* bias, int cout, const float* head_w, const float* head_b,
+                   float* logits, float* probs, int N, int H, int W, int kh, int kw, int relu, int dtype, void* stream) {
+  DN_CHECK_ARG(x.base && packed_w && head_w && head_b && (logits || probs), "dn_conv2d_head: null pointer");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d_head: bad dtype %d", dtype);
+  if (!head_fits(x.channels, cout, N, H, W, kh, kw, dtype))
+    return dn_set_error(DN_ERR_UNSUPPORTED, "dn_conv2d_head: no single-tile kernel for cout=%d at N=%d H=%d W=%d k=(%d,%d); "
+                        "use dn_conv2d + dn_head_1x1", cout, N, H, W, kh, kw);
+  const int xp = dn_planes(x.channels, dtype);
+  DN_CHECK_ARG(x.plane0 >= 0 && x.plane0 + xp <= x.planes_total, "dn_conv2d_head: x planes [%d,%d) outside buffer of %d",
+               x.plane0, x.plane0 + xp, x.planes_total);
+  ConvParams p{};
+  p.x = x.base; p.x_planes_total = x.planes_total; p.x_plane0 = x.plane0; p.x_nplanes = xp; p.x_gplanes = 1 << 30; p.x_wmul = 1;
+  p.w = packed_w; p.bias = bias;
+  p.y = nullptr; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.N = N; p.H = H; p.W = W; p.nchunk = xp; p.cout_pad = dn_channel_pad(cout); p.relu = relu;
+  p.head_w = head_w; p.head_b = head_b; p.head_logits = logits; p.head_probs = probs;
+  return run_igemm(p, kh, kw, dtype, (hipStream_t)stream);
+}
 
 int dn_conv2d_pool(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, dn_tensor pooled, int N, int H, int W,
                    int kh, int kw, int relu, int dtype, void* stream) {

@@ -31,6 +31,8 @@ struct ConvParams {
   int ntw, nth;             // column / row tiles per image
   float* stats;             // BatchNorm partial sums [pixel tile][cout_pad][2] (CONV_EPI_STATS instantiations), else unused
   void* pool; int pool_planes_total, pool_plane0;   // MaxPool2d((1,2)) of y, W/2 columns (CONV_EPI_POOL), else unused
+  const float* head_w; const float* head_b;         // 1x1 head over the tile's channels (CONV_EPI_HEAD): y is not stored,
+  float* head_logits; float* head_probs;            // logits / sigmoid go to [N][H][W] fp32 (either may be null)
 #ifdef C8_PROFILE_WAIT
   long long* dbg;           // [waves][3]: cycles in vmcnt waits, in barriers, total (scratch/conv8_micro.hip)
 #endif
@@ -57,6 +59,51 @@ template <> struct Mma32<float> {
 constexpr int CONV_EPI_PLAIN = 0;   // nothing
 constexpr int CONV_EPI_STATS = 1;   // + BatchNorm batch statistics of y (training forward)
 constexpr int CONV_EPI_POOL = 2;    // + MaxPool2d((1,2)) of y into a second buffer (encoder blocks, eval mode)
+constexpr int CONV_EPI_HEAD = 3;    // instead of storing y: the 1x1 output convolution + sigmoid over it (last block, eval mode)
+
+// Head form of the epilogue (unet_architecture.py:94-97 + trainable_unet.py:409 fused into the last DoubleConv): the
+// block holds every channel of its pixels (cout_pad == COT), a lane 16 of them, so logit = sum_c w_c * act_c + b is a
+// 16-term dot product per lane plus one exchange between the wave halves.  The activation is rounded to the storage
+// type first, i.e. the head sees what it would have read back from HBM; 64 B/pixel of writes become 4 (or 8).
+template <typename T, int HT, int COT>
+__device__ __forceinline__ void conv_epilogue_head(const ConvParams& p, f32x16_t (&acc)[HT][COT / 32], int n, int h0, int wbase,
+                                                   int lane) {
+  constexpr int NCG = COT / 32;
+  const int l31 = lane & 31, half = lane >> 5;
+  float bias_r[NCG][16], hw[NCG][16];
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = cg * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+      bias_r[cg][r] = p.bias ? p.bias[ch] : 0.f;
+      hw[cg][r] = p.head_w[ch];
+    }
+  const float hb = p.head_b[0];
+#pragma unroll
+  for (int hh = 0; hh < HT; ++hh) {
+    const int h = h0 + hh;
+    if (h < p.H) {                                    // block-uniform
+      float dot = 0.f;
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[hh][cg][r] + bias_r[cg][r];
+          if (p.relu) v = fmaxf(v, 0.f);
+          if constexpr (sizeof(T) == 2) v = (float)(__bf16)v;
+          dot = fmaf(v, hw[cg][r], dot);
+        }
+      dot += __shfl_xor(dot, 32);
+      if (half == 0 && wbase + l31 < p.W) {
+        const long idx = ((long)n * p.H + h) * p.W + wbase + l31;
+        const float z = dot + hb;
+        if (p.head_logits) p.head_logits[idx] = z;
+        if (p.head_probs) p.head_probs[idx] = 1.f / (1.f + expf(-z));
+      }
+    }
+  }
+}
 
 // Epilogue shared by the 4-wave and 8-wave kernels: bias (+ folded BN) + ReLU in registers, then through a wave-private
 // LDS scratch so that every global store instruction writes 1 KiB of consecutive 16-byte pieces (32 pixels of one
@@ -386,8 +433,9 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   constexpr int NPL = COT / EPR;                    // planes of the tile's channels = KiB of scratch per wave
   float* stat_lds = (float*)(smem_all + 4 * NPL * 1024);            // [wave][COT][2], past every wave's scratch
   unsigned char* pool_lds = smem_all + 4 * NPL * 1024 + 4 * COT * 2 * 4;   // [wave][NPL][512 B]
-  conv_epilogue_store<T, HT, COT, EPI>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
-                                       pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
+  if constexpr (EPI == CONV_EPI_HEAD) conv_epilogue_head<T, HT, COT>(p, acc, n, h0, w0 + 32 * wave, lane);
+  else conv_epilogue_store<T, HT, COT, EPI>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
+                                            pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
   if constexpr (STATS) {
     // BatchNorm statistics of this tile: partial[pixel tile][channel][sum, sum of squares] (bn_finalize_kernel's layout)
     __syncthreads();

@@ -12,6 +12,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence
 
 import ctypes
+import os
 
 import torch
 
@@ -210,8 +211,24 @@ class HipUNet(ParameterTree):
             tmp = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
             both = cat[l].ref(2 * self._cpad_planes(c[l]), 0)
             self._conv(units[pre + ".0"], cache[pre + ".0"], both, tmp.ref(c[l]), n, h, ws[l])
+            last = units[pre + ".3"]
+            kh, kw = self.kernel_size
+            if l == 0 and not os.environ.get("DN_TUNE_NO_HEAD_FUSE") and hip.lib.dn_conv2d_head_supported(last.cin, last.cout, n, h, w, kh, kw, dt):
+                # the 1x1 output convolution + sigmoid ride in the last convolution's epilogue: its activation is never stored
+                entry = cache[pre + ".3"]
+                if self.profile is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                hip.check(hip.lib.dn_conv2d_head(tmp.ref(c[0]), hip.ptr(entry["w"]), hip.ptr(entry["bias"]), last.cout,
+                                                 hip.ptr(cache["head_w"]), hip.ptr(cache["head_b"]), hip.ptr(logits),
+                                                 hip.ptr(probs), n, h, w, kh, kw, 1, dt, hip.stream_ptr()))
+                if self.profile is not None:
+                    e1.record()
+                    self.profile.append((self.conv_kernel_tag(last.cin, last.cout, n, h, w) + "+head",
+                                         2.0 * n * h * w * last.cout * (last.cin * kh * kw + 1), e0, e1))
+                return
             out = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
-            self._conv(units[pre + ".3"], cache[pre + ".3"], tmp.ref(c[l]), out.ref(c[l]), n, h, ws[l])
+            self._conv(last, cache[pre + ".3"], tmp.ref(c[l]), out.ref(c[l]), n, h, ws[l])
             cur = out
         hip.check(hip.lib.dn_head_1x1(cur.ref(c[0]), hip.ptr(cache["head_w"]), hip.ptr(cache["head_b"]),
                                       hip.ptr(logits), hip.ptr(probs), n, h, w, dt, hip.stream_ptr()))

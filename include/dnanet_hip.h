@@ -43,6 +43,12 @@ typedef struct dn_tensor {
   int channels;      /* logical channel count C */
 } dn_tensor;
 
+/* return codes (common.h has the same values under DN_OK / DN_ERR_*) */
+#define DN_STATUS_OK 0
+#define DN_STATUS_BAD_ARGUMENT 1
+#define DN_STATUS_UNSUPPORTED 2   /* no kernel built for this shape / kernel size / mode */
+#define DN_STATUS_HIP_ERROR 3
+
 const char* dn_last_error(void);
 int dn_abi_version(void);
 static inline int dn_channel_pad(int c) { return (c + 31) / 32 * 32; }
@@ -120,6 +126,15 @@ int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const flo
  * columns.  Kernel sizes (3,5) and (1,3); W even. */
 int dn_conv2d_pool(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, dn_tensor pooled, int N, int H, int W,
                    int kh, int kw, int relu, int dtype, void* stream);
+/* The last DoubleConv convolution with the output head fused: nn.Conv2d(C, 1, 1) (unet_architecture.py:94-97) and
+ * torch.sigmoid (trainable_unet.py:409) are applied to the block's channels in the epilogue; the C-channel activation is
+ * never written.  bias / packed_w as for dn_conv2d (eval-mode BatchNorm folded), head_w: [dn_channel_pad(cout)] zero
+ * padded, head_b: [1]; logits / probs: [N][1][H][W] fp32, either may be null.  Needs the kernel tile to span all output
+ * channels (cout <= 64 and a shape the dispatcher gives such a tile): dn_conv2d_head_supported says so beforehand,
+ * otherwise DN_STATUS_UNSUPPORTED and the caller runs dn_conv2d + dn_head_1x1. */
+int dn_conv2d_head_supported(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype);
+int dn_conv2d_head(dn_tensor x, const void* packed_w, const float* bias, int cout, const float* head_w, const float* head_b,
+                   float* logits, float* probs, int N, int H, int W, int kh, int kw, int relu, int dtype, void* stream);
 /* The convolution of a DoubleConv in training mode (nn.Conv2d + bias feeding nn.BatchNorm2d, unet_architecture.py:14-17)
  * with the BatchNorm batch statistics taken in the convolution's epilogue: y as dn_conv2d(relu = 0), and per pixel tile
  * and channel the sum and sum of squares of the values as stored, partial[tile][dn_channel_pad(cout)][2]

@@ -142,6 +142,46 @@ def test_conv2d(gpu_device, case, dtype, ints):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(2, 32, 32, 5, 64, 3, 5), (3, 16, 24, 6, 200, 3, 5), (130, 32, 64, 5, 512, 3, 5),
+                                  (1, 32, 8, 3, 128, 3, 5), (2, 16, 24, 5, 130, 1, 3), (130, 32, 32, 6, 512, 3, 5)])
+def test_conv2d_head(gpu_device, case, dtype):
+    """dn_conv2d_head = dn_conv2d (ReLU) followed by dn_head_1x1, without the activation in between: logits on integer
+    data are exact, probabilities are their sigmoid; shapes whose tile does not span the channels are refused."""
+    hip = _hip()
+    n, cin, cout, h, w, kh, kw = case
+    g = torch.Generator().manual_seed(31 + dtype)
+    x = torch.randint(-2, 3, (n, cin, h, w), generator=g).float()
+    wt = torch.randint(-1, 2, (cout, cin, kh, kw), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    hw = torch.randint(-2, 3, (cout,), generator=g).float()
+    hb = torch.tensor([0.5])
+    act = _q(F.conv2d(x, wt, b, padding=(kh // 2, kw // 2)).relu(), dtype)
+    want = (act * hw.view(1, -1, 1, 1)).sum(1, keepdim=True) + hb
+    assert float(want.abs().max()) < 2 ** 23                       # integer sums stay exact in fp32
+    xb = hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype)
+    packed = _pack(hip, wt, None, hip.PACK_FWD, dtype, gpu_device)
+    cp = hip.channel_pad(cout)
+    bias, hwp, hbd = _padvec(b, cp, gpu_device), _padvec(hw, cp, gpu_device), hb.to(gpu_device)
+    assert hip.lib.dn_conv2d_head_supported(cin, cout, n, h, w, kh, kw, dtype) == 1
+    logits = torch.full((n, 1, h, w), float("nan"), device=gpu_device)
+    probs = torch.full((n, 1, h, w), float("nan"), device=gpu_device)
+    hip.check(hip.lib.dn_conv2d_head(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), cout, hip.ptr(hwp), hip.ptr(hbd),
+                                     hip.ptr(logits), hip.ptr(probs), n, h, w, kh, kw, 1, dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(logits.cpu(), want)
+    assert torch.allclose(probs.cpu(), torch.sigmoid(want), rtol=1e-6, atol=1e-7)
+    # logits only
+    only = torch.zeros_like(logits)
+    hip.check(hip.lib.dn_conv2d_head(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), cout, hip.ptr(hwp), hip.ptr(hbd),
+                                     hip.ptr(only), None, n, h, w, kh, kw, 1, dtype, hip.stream_ptr()))
+    assert torch.equal(only, logits)
+    # 128 output channels never fit one tile
+    assert hip.lib.dn_conv2d_head_supported(cin, 128, n, h, w, kh, kw, dtype) == 0
+    assert hip.lib.dn_conv2d_head(xb.ref(cin), hip.ptr(packed), hip.ptr(bias), 128, hip.ptr(hwp), hip.ptr(hbd),
+                                  hip.ptr(only), None, n, h, w, kh, kw, 1, dtype, hip.stream_ptr()) == 2
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 32, 32, 5, 64, 3, 5), (3, 16, 24, 6, 200, 3, 5), (2, 64, 72, 5, 300, 3, 5),
                                   (1, 32, 128, 3, 128, 3, 5), (2, 16, 40, 5, 130, 1, 3), (130, 32, 32, 5, 512, 3, 5),
                                   (8, 64, 512, 5, 2048, 3, 5), (8, 64, 512, 6, 2048, 3, 5)])   # the last two: 8-wave kernels
