@@ -242,7 +242,9 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
 // with both.  The choice is per block, so the chunk loop exists in four compile-time variants and each block runs
 // one; inside a variant the MFMA loop has no branches, so the fragment reads and MFMAs of a whole chunk are
 // scheduled as one basic block.
-template <typename T, int KH, int KW, int HT, int COT, int EPI = CONV_EPI_PLAIN, int MINB = 2>
+// KP = K planes (chunks) staged and consumed per barrier: a 1x1 GEMM has only HT * COT/32 MFMAs per wave and plane, too
+// few to pay for a barrier each.
+template <typename T, int KH, int KW, int HT, int COT, int EPI = CONV_EPI_PLAIN, int MINB = 2, int KP = 1>
 __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams p) {
   constexpr bool STATS = EPI == CONV_EPI_STATS;
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
@@ -253,9 +255,11 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   constexpr int ACT_RAW = ROWS * QW * 32;
   constexpr int ACT_BYTES = (ACT_RAW + 1023) / 1024 * 1024;          // weight image starts on a 1-KiB piece boundary
   constexpr int W_BYTES = TAPS * COT * 32;
-  constexpr int ST_ITERS = (ACT_BYTES + W_BYTES + 4095) / 4096;      // wave-instructions of 1 KiB per wave
+  constexpr int PL_ITERS = (ACT_BYTES + W_BYTES + 4095) / 4096;      // wave-instructions of 1 KiB per wave and plane
+  constexpr int PL_BYTES = PL_ITERS * 4096;                          // LDS image of one plane
+  constexpr int ST_ITERS = KP * PL_ITERS;
   constexpr int EPI_BYTES = 4 * (COT / EPR) * 1536 + 4 * COT * 2 * 4;  // epilogue: 4 waves x COT channels (+ pooled) + statistics
-  constexpr int BUF_BYTES = ST_ITERS * 4096;
+  constexpr int BUF_BYTES = KP * PL_BYTES;
   // K chunks are software pipelined through NBUF LDS images when two workgroups of them fit a CU (1x1 / 1x3 kernels:
   // a chunk is only HT*NCG MFMAs per wave, far less than a load latency); the 3x5 images are too big for that and
   // rely on the CU's other workgroup to cover their load phase.
@@ -291,11 +295,11 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   // per-thread staging plan: LDS piece P = (it*4 + wave)*64 + lane of the linear image [act tile | pad | weight tile];
   // st_off[it] = byte offset of its source inside the current plane / weight block, DN_OOB = zero fill.  The tile
   // position is fixed for the block, so the plan is made once and a chunk costs SALU work only (two SRD bases).
-  unsigned st_off[ST_ITERS];
+  unsigned st_off[PL_ITERS];
   {
     const int xrow_b = p.W * p.x_wmul * 32;
 #pragma unroll
-    for (int it = 0; it < ST_ITERS; ++it) {
+    for (int it = 0; it < PL_ITERS; ++it) {
       const int byte = ((it * 4 + wave) * 64 + lane) * 16;
       unsigned off = DN_OOB;
       if (byte < ACT_RAW) {
@@ -328,7 +332,10 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   // LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the per-lane SOURCE offset
   // (cdna_hip_programming.md, rule 21).  A chunk that does not exist (past the end, or the padding plane of a virtual
   // group, whose weights are zero) is staged from an empty buffer = all zeros, which keeps loops and vmcnt uniform.
-  auto stage = [&](int ck, int buf) {
+  auto stage = [&](int ckp, int buf) {
+#pragma unroll
+   for (int kp = 0; kp < KP; ++kp) {
+    const int ck = ckp * KP + kp;
     const int grp = ck / p.x_gplanes;
     const int plane = ck - grp * p.x_gplanes;
     const bool exists = ck < p.nchunk && plane < p.x_nplanes;
@@ -338,12 +345,13 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
     if (!exists) { srd_x.z = 0; srd_w.z = 0; }
 #ifndef CV_ABLATE_NO_STAGE   // (ablation hooks: scratch/conv_micro.hip)
 #pragma unroll
-    for (int it = 0; it < ST_ITERS; ++it) {
+    for (int it = 0; it < PL_ITERS; ++it) {
       const bool is_w = (it * 4 + wave) * 1024 >= ACT_BYTES;          // wave-uniform
       dn_buffer_lds16(st_off[it], is_w ? srd_w : srd_x,
-                      __builtin_amdgcn_readfirstlane(smem_lds + buf * BUF_BYTES + (it * 4 + wave) * 1024));
+                      __builtin_amdgcn_readfirstlane(smem_lds + buf * BUF_BYTES + kp * PL_BYTES + (it * 4 + wave) * 1024));
     }
 #endif
+   }
   };
 
 #pragma unroll
@@ -355,7 +363,8 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   auto mainloop = [&](auto skip_top_c, auto skip_bot_c) {
   constexpr bool SKIP_TOP = decltype(skip_top_c)::value, SKIP_BOT = decltype(skip_bot_c)::value;
   int buf = 0;
-  for (int ck = 0; ck < p.nchunk; ++ck, buf = buf + 1 == NBUF ? 0 : buf + 1) {
+  const int nsteps = (p.nchunk + KP - 1) / KP;
+  for (int ck = 0; ck < nsteps; ++ck, buf = buf + 1 == NBUF ? 0 : buf + 1) {
     if constexpr (NBUF == 1) {
 #ifdef C8_PROFILE_WAIT
       const long long tp0 = clock64();
@@ -373,7 +382,9 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
       __syncthreads();   // everyone's pieces of chunk ck landed; everyone left the image of chunk ck-1
       stage(ck + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
     }
-    const unsigned char* smem = smem_all + buf * BUF_BYTES;
+#pragma unroll
+   for (int kp = 0; kp < KP; ++kp) {
+    const unsigned char* smem = smem_all + buf * BUF_BYTES + kp * PL_BYTES;
     // ---- MFMA over all taps
 #ifndef CV_ABLATE_NO_COMPUTE
 #pragma unroll
@@ -405,6 +416,7 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
 #else
     (void)smem;
 #endif
+   }
   }
 
   };
@@ -448,14 +460,14 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   }
 }
 
-template <typename T, int KH, int KW, int HT, int COT, int EPI = CONV_EPI_PLAIN, int MINB = 2>
+template <typename T, int KH, int KW, int HT, int COT, int EPI = CONV_EPI_PLAIN, int MINB = 2, int KP = 1>
 int conv_igemm_launch(ConvParams p, hipStream_t stream) {
   p.ntw = (p.W + 127) / 128;
   p.nth = (p.H + HT - 1) / HT;
   const long blocks = ((long)p.N * p.ntw * p.nth + 7) / 8 * 8 * (p.cout_pad / COT);
   if (blocks <= 0 || blocks > 0x7fffffffL) return dn_set_error(DN_ERR_ARG, "conv grid out of range: %ld blocks", blocks);
   if ((long)p.H * p.W * p.x_wmul * 32 >= (1L << 31)) return dn_set_error(DN_ERR_ARG, "conv: one plane exceeds 2 GiB");
-  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, EPI, MINB>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, HT, COT, EPI, MINB, KP>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

@@ -278,7 +278,8 @@ def test_conv2d_dgrad(gpu_device, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-@pytest.mark.parametrize("case", [(2, 64, 32, 5, 64), (1, 32, 16, 6, 48), (2, 128, 64, 5, 128), (1, 16, 8, 5, 32)])
+@pytest.mark.parametrize("case", [(2, 64, 32, 5, 64), (1, 32, 16, 6, 48), (2, 128, 64, 5, 128), (1, 16, 8, 5, 32),
+                                  (2, 48, 64, 6, 256), (2, 128, 40, 6, 256)])   # 128-row tiles, two K planes per barrier (odd / even plane counts)
 def test_conv_transpose(gpu_device, case, dtype):
     hip = _hip()
     n, cin, cout, h, win = case
