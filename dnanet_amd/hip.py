@@ -72,6 +72,7 @@ _SIGS = {
     "dn_i16_to_f32": (c_int, [_P, _P, c_long, _P]),
     "dn_pack_jobs_prepare": (c_long, [_P, c_int, c_int]),
     "dn_pack_batched": (c_int, [_P, c_int, c_long, c_int, _P]),
+    "dn_rescale_profiles": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "dn_pixel_confusion": (c_int, [_P, _P, c_int, c_long, c_float, c_float, _P, _P]),
     "dn_conv2d_variant": (c_int, [c_int] * 8 + [ctypes.c_char_p, c_int]),
     "dn_conv2d_pool": (c_int, [DnTensor, _P, _P, DnTensor, DnTensor, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

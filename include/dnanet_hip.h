@@ -205,6 +205,15 @@ int dn_call_alleles(const float* probs, const float* rfu, const double* scaler, 
                     const int* table_order, const int* table_off, int N, int H, int W, int amax, int* out_rfu, int* out_first,
                     void* stream);
 
+/* ---- ingest ------------------------------------------------------------------------------------
+ * rescale_dye (DNAnet/data/utils.py:239-279) + HIDImage._rescale_profile / the scaler (hid_image.py:111,168-183) for a
+ * batch: raw [n][rows][length] fp32 RFU, basepairs [n][length] float64 = get_interpolated_basepairs of each size standard
+ * (0 outside the ladder), span [n][2] = first / last scan of the ladder, target [n_out] float64 = linspace(65, 475, 4096).
+ * out [n][1][rows][n_out] fp32 (the network's input layout), scaler [n][n_out] float64, idx_out (nullable) [n][n_out] the
+ * chosen raw scan per output scan. */
+int dn_rescale_profiles(const float* raw, const double* basepairs, const int* span, const double* target, int n_profiles,
+                        int rows, int length, int n_out, float* out, double* scaler, int* idx_out, void* stream);
+
 /* Pixel metrics (DNAnet/evaluation/segmentation/pixel_metrics.py:9-74) from the probability maps still in HBM: per
  * profile counts[i][0..2] = { tp, fp, fn } with "predicted positive" = p >= thr_ge (pixel_precision / recall / F1,
  * :17-36), counts[i][3..5] the same with p > thr_gt (average_binary_iou, :65).  truth: int8, 1 / 0, other values count
