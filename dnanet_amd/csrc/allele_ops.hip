@@ -57,29 +57,31 @@ __global__ __launch_bounds__(AL_THREADS) void allele_runs_kernel(const float* __
 
 // Pixel confusion counts of one profile per block (pixel_metrics.py:9-74): a pixel is predicted positive when
 // p >= thr_ge (precision / recall / F1) resp. p > thr_gt (IoU); truth is 1 / 0, anything else counts for neither class.
-// counts[image] = { tp, fp, fn } for ">=" followed by { tp, fp, fn } for ">".  Integer sums: order independent.
+// counts[image] = { tp, fp, fn } for ">=", { tp, fp, fn } for ">", then the number of truth values that are neither 0 nor 1
+// (a mask the caller should not use these counts for).  Integer sums: order independent.
 __global__ __launch_bounds__(256) void pixel_confusion_kernel(const float* __restrict__ probs, const signed char* __restrict__ truth,
                                                               long pixels, float thr_ge, float thr_gt, int* __restrict__ counts) {
   const float* p = probs + (long)blockIdx.x * pixels;
   const signed char* t = truth + (long)blockIdx.x * pixels;
-  int c[6] = {0, 0, 0, 0, 0, 0};
+  int c[7] = {0, 0, 0, 0, 0, 0, 0};
   for (long i = threadIdx.x; i < pixels; i += 256) {
     const float pv = p[i];
     const int one = t[i] == 1, zero = t[i] == 0;
     const int ge = pv >= thr_ge, gt = pv > thr_gt;
     c[0] += ge & one; c[1] += ge & zero; c[2] += (ge ^ 1) & one;
     c[3] += gt & one; c[4] += gt & zero; c[5] += (gt ^ 1) & one;
+    c[6] += (one | zero) ^ 1;
   }
-  __shared__ int red[4][6];
+  __shared__ int red[4][7];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < 7; ++k) {
     int v = c[k];
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 6) counts[blockIdx.x * 6 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 7) counts[blockIdx.x * 7 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 }  // namespace

@@ -407,7 +407,8 @@ class DNANet_UNet(TrainableModel):
         counts = self._pixel_counts(batch, probs)
         if counts is not None:       # annotated profiles: the pixel metrics' confusion counts from the same pass
             for i, pred in enumerate(predictions):
-                pred._pixel_counts = (id(batch[i]), 0.5, tuple(int(c) for c in counts[i]))
+                if counts[i, 6] == 0:                 # a 0/1 mask
+                    pred._pixel_counts = (id(batch[i]), 0.5, tuple(int(c) for c in counts[i, :6]))
         if self.allele_caller:
             LOGGER.info("Calling alleles from predicted segmentation...")
             if hasattr(self.allele_caller, "call_alleles_batch"):
@@ -420,17 +421,24 @@ class DNANet_UNet(TrainableModel):
     def _pixel_counts(self, batch: Sequence, probs: torch.Tensor) -> Optional[np.ndarray]:
         """On-device metrics: per profile {tp, fp, fn} at ``p >= 0.5`` and at ``p > 0.5`` against the
         annotation, computed from the probability maps while they are in HBM (``dn_pixel_confusion``).  Only for
-        batches whose every annotation is a 0/1 mask of the output's shape; otherwise None and
-        ``dnanet_amd.metrics`` makes its boolean passes on the host, like the reference."""
+        annotations that are 0/1 masks of the output's shape; for the others ``dnanet_amd.metrics`` makes its boolean
+        passes on the host, like the reference."""
         try:
             truth = np.stack([np.asarray(im.annotation.image) for im in batch])              # (N,H,W,1)
         except (AttributeError, ValueError, TypeError):
             return None
-        if truth.size != probs.numel() or truth.dtype.kind not in "iubf" or not np.isin(truth, (0, 1)).all():
+        if truth.size != probs.numel() or truth.dtype.kind not in "iubf":
             return None
-        truth = np.ascontiguousarray(np.transpose(truth, (0, 3, 1, 2)).astype(np.int8))
+        # int8 with everything that is not exactly 0 / 1 mapped to "other" (the kernel counts those per profile)
+        if truth.dtype.kind == "f":
+            truth = np.where(truth == 1, 1, np.where(truth == 0, 0, 2)).astype(np.int8)
+        elif truth.dtype.itemsize > 1:
+            truth = np.clip(truth, -1, 2).astype(np.int8)
+        else:
+            truth = truth.astype(np.int8, copy=False)            # uint8 values >= 128 wrap to negatives: still "other"
+        truth = np.ascontiguousarray(np.transpose(truth, (0, 3, 1, 2)))
         truth_dev = torch.from_numpy(truth).to(probs.device)
-        counts = torch.empty((len(batch), 6), dtype=torch.int32, device=probs.device)
+        counts = torch.empty((len(batch), 7), dtype=torch.int32, device=probs.device)
         hip.check(hip.lib.dn_pixel_confusion(hip.ptr(probs), hip.ptr(truth_dev), len(batch), probs[0].numel(), 0.5, 0.5,
                                              hip.ptr(counts), hip.stream_ptr()))
         return counts.cpu().numpy()

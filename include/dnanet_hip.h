@@ -216,8 +216,9 @@ int dn_rescale_profiles(const float* raw, const double* basepairs, const int* sp
 
 /* Pixel metrics (DNAnet/evaluation/segmentation/pixel_metrics.py:9-74) from the probability maps still in HBM: per
  * profile counts[i][0..2] = { tp, fp, fn } with "predicted positive" = p >= thr_ge (pixel_precision / recall / F1,
- * :17-36), counts[i][3..5] the same with p > thr_gt (average_binary_iou, :65).  truth: int8, 1 / 0, other values count
- * for neither class.  probs, truth: [n_images][pixels]. */
+ * :17-36), counts[i][3..5] the same with p > thr_gt (average_binary_iou, :65), counts[i][6] = truth values that are
+ * neither 0 nor 1 (they count for neither class; the IoU of such a mask is not given by these counts).  truth: int8.
+ * probs, truth: [n_images][pixels]; counts: [n_images][7]. */
 int dn_pixel_confusion(const float* probs, const signed char* truth, int n_images, long pixels, float thr_ge, float thr_gt,
                        int* counts, void* stream);
 

@@ -234,9 +234,14 @@ def test_device_pixel_counts_equal_host_metrics(gpu_device):
     from dnanet_amd import hip
     probs = torch.tensor([[0.5, 0.5, 0.7, 0.2, 0.49999997, 0.9, 0.1, 0.5]], device="cuda")
     truth = torch.tensor([[1, 0, 1, 1, 0, 0, 0, 2]], dtype=torch.int8, device="cuda")
-    counts = torch.zeros((1, 6), dtype=torch.int32, device="cuda")
+    counts = torch.zeros((1, 7), dtype=torch.int32, device="cuda")
     hip.check(hip.lib.dn_pixel_confusion(hip.ptr(probs), hip.ptr(truth), 1, 8, 0.5, 0.5, hip.ptr(counts), hip.stream_ptr()))
-    assert counts.cpu().tolist() == [[2, 2, 1, 1, 1, 2]]
-    # annotations that are not 0/1 masks: no device counts, host path as before
+    assert counts.cpu().tolist() == [[2, 2, 1, 1, 1, 2, 1]]
+    # an annotation that is not a 0/1 mask: no device counts for that profile, host path as before; float 0/1 masks are fine
     images[0].annotation.image = images[0].annotation.image.astype(np.float64) * 0.5
-    assert not any(hasattr(p, "_pixel_counts") for p in model.predict_batch(images))
+    images[1].annotation.image = images[1].annotation.image.astype(np.float64)
+    again = model.predict_batch(images)
+    assert not hasattr(again[0], "_pixel_counts") and all(hasattr(p, "_pixel_counts") for p in again[1:])
+    bare = [Prediction(image=p.image, meta=p.meta) for p in again]
+    for name, fn in M.METRICS.items():
+        assert fn(images=images, predictions=again) == fn(images=images, predictions=bare), name
