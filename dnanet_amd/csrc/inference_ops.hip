@@ -222,11 +222,44 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const dn_pack_job* __
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+// matrix-core path (conv_first_mfma.hip), optionally with BatchNorm statistics
+static int conv_first_impl(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout, int kh,
+                           int kw, int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream) {
+  const int yp = dn_planes(cout, dtype);
+  DN_CHECK_ARG(y.plane0 >= 0 && y.plane0 + yp <= y.planes_total, "dn_conv_first: y planes [%d,%d) outside buffer of %d", y.plane0,
+               y.plane0 + yp, y.planes_total);
+  ConvParams p{};
+  p.bias = bias;
+  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.N = N; p.H = H; p.W = W; p.cout_pad = dn_channel_pad(cout); p.relu = relu;
+  if (stats) {
+    const int ht = conv_first_row_tile(H);
+    const long tiles = (long)N * ((H + ht - 1) / ht) * ((W + 127) / 128);
+    DN_CHECK_ARG(tiles * p.cout_pad * 2 <= stats_capacity, "dn_conv_first_stats: partial buffer of %ld floats, need %ld",
+                 stats_capacity, tiles * p.cout_pad * 2);
+    p.stats = stats;
+    *ntiles = (int)tiles;
+  }
+  return conv_first_mfma_run(x, wf, p, kh, kw, dtype, (hipStream_t)stream);
+}
+
+int dn_conv_first_stats(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout, int kh,
+                        int kw, int dtype, float* partial, long partial_floats, int* ntiles, void* stream) {
+  DN_CHECK_ARG(x && wf && y.base && partial && ntiles, "dn_conv_first_stats: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && cout > 0 && y.channels == cout, "dn_conv_first_stats: bad shape");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_first_stats: bad dtype %d", dtype);
+  DN_CHECK_ARG((kh == 3 && kw == 5) || (kh == 1 && kw == 3), "dn_conv_first_stats: kernel size (%d,%d) has no statistics epilogue", kh, kw);
+  return conv_first_impl(x, wf, bias, y, N, H, W, cout, kh, kw, 0, dtype, partial, partial_floats, ntiles, stream);
+}
+
 int dn_conv_first(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout, int kh,
                   int kw, int relu, int dtype, void* stream) {
   DN_CHECK_ARG(x && wf && y.base, "dn_conv_first: null pointer");
   DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && cout > 0, "dn_conv_first: bad shape N=%d H=%d W=%d cout=%d", N, H, W, cout);
   DN_CHECK_ARG(y.channels == cout, "dn_conv_first: y.channels=%d != cout=%d", y.channels, cout);
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_first: bad dtype %d", dtype);
+  if ((kh == 3 && kw == 5) || (kh == 1 && kw == 3))
+    return conv_first_impl(x, wf, bias, y, N, H, W, cout, kh, kw, relu, dtype, nullptr, 0, nullptr, stream);
   if (dtype == DN_BF16) return conv_first_t<__bf16>(x, wf, bias, y, N, H, W, cout, kh, kw, relu, (hipStream_t)stream);
   if (dtype == DN_F32) return conv_first_t<float>(x, wf, bias, y, N, H, W, cout, kh, kw, relu, (hipStream_t)stream);
   return dn_set_error(DN_ERR_ARG, "dn_conv_first: bad dtype %d", dtype);

@@ -344,16 +344,22 @@ class HipUNet(ParameterTree):
                    hip.ptr(self.tensor(u.bn + ".running_mean")), hip.ptr(self.tensor(u.bn + ".running_var")), BN_MOMENTUM, BN_EPS,
                    hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift))
         kh, kw = self.kernel_size
-        if u.cin != 1 and (kh, kw) in ((3, 5), (1, 3)) and self.profile is None:
+        if (kh, kw) in ((3, 5), (1, 3)) and self.profile is None:
             # the batch statistics come out of the convolution's epilogue: one pass over y saved
-            need = n * ((h + 2) // 3) * ((w + 127) // 128) * cp * 2          # tiles are at least 3 rows x 128 columns
+            # tiles are at least 3 rows x 128 columns (the first convolution may tile row by row)
+            need = n * (h if u.cin == 1 else (h + 2) // 3) * ((w + 127) // 128) * cp * 2
             if ws.get("bnstat") is None or ws["bnstat"].numel() < need:
                 ws["bnstat"] = torch.empty(need, dtype=torch.float32, device=self.device)
             ntiles = ctypes.c_int(0)
             entry = cache[u.conv]
-            hip.check(hip.lib.dn_conv2d_stats(src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, kh, kw,
-                                              self.dtype, hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles),
-                                              hip.stream_ptr()))
+            if u.cin == 1:
+                hip.check(hip.lib.dn_conv_first_stats(hip.ptr(raw_x), hip.ptr(entry["wf"]), hip.ptr(entry["bias"]), y.ref(u.cout),
+                                                      n, h, w, u.cout, kh, kw, self.dtype, hip.ptr(ws["bnstat"]),
+                                                      ws["bnstat"].numel(), ctypes.byref(ntiles), hip.stream_ptr()))
+            else:
+                hip.check(hip.lib.dn_conv2d_stats(src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, kh, kw,
+                                                  self.dtype, hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles),
+                                                  hip.stream_ptr()))
             hip.check(hip.lib.dn_bn_train_apply(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["bnstat"]), ntiles.value,
                                                 self.dtype, hip.stream_ptr()))
         else:

@@ -88,6 +88,10 @@ int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, in
  * wf: [kh*kw][dn_channel_pad(cout)] fp32 (BN scale already folded in for inference), bias likewise. */
 int dn_conv_first(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout, int kh,
                   int kw, int relu, int dtype, void* stream);
+/* dn_conv_first without ReLU plus the BatchNorm batch statistics of its output, as dn_conv2d_stats (training forward of the
+ * first DoubleConv unit). */
+int dn_conv_first_stats(const float* x, const float* wf, const float* bias, dn_tensor y, int N, int H, int W, int cout, int kh,
+                        int kw, int dtype, float* partial, long partial_floats, int* ntiles, void* stream);
 /* nn.Conv2d(cin, cout, (kh,kw), padding=k//2) [+ folded BatchNorm2d + ReLU when relu=1]
  * (unet_architecture.py:14-21): y = act(conv(x, packed_w) + bias).  packed_w from DN_PACK_FWD, or
  * DN_PACK_DGRAD to compute the data gradient (then x = dy, cin/cout swapped by the caller). */

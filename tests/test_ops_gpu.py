@@ -339,6 +339,51 @@ def test_conv_first(gpu_device, dtype, k):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 5, 300, 24), (3, 6, 256, 64), (2, 3, 128, 32), (2, 7, 200, 8), (1, 10, 4096, 32)])
+@pytest.mark.parametrize("k", [(3, 5), (1, 3)])
+def test_conv_first_exact_and_stats(gpu_device, dtype, shape, k):
+    """The matrix-core first convolution on integer data (exact in fp32 accumulation; raw-RFU-sized inputs), every row
+    tiling (5 / 6 / 3 / 1 rows), several channel tiles; dn_conv_first_stats gives the same y without ReLU plus per-tile
+    sums whose totals equal a pass over the stored y."""
+    import ctypes
+    hip = _hip()
+    kh, kw = k
+    n, h, w, cout = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randint(0, 30000, (n, 1, h, w), generator=g).float()
+    wt = torch.randint(-2, 3, (cout, 1, kh, kw), generator=g).float()
+    b = torch.randint(-3, 4, (cout,), generator=g).float()
+    ref = F.conv2d(x, wt, b, padding=(kh // 2, kw // 2))
+    cp = hip.channel_pad(cout)
+    wf = torch.zeros(kh * kw, cp)
+    wf[:, :cout] = wt.view(cout, kh * kw).t()
+    xd, wd, bd = x.to(gpu_device), wf.to(gpu_device), _padvec(b, cp, gpu_device)
+    yb = hip.PlaneBuffer(n, hip.planes(cout, dtype) + 2, h, w, dtype, gpu_device, zero=True)
+    hip.check(hip.lib.dn_conv_first(hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), yb.ref(cout, 1), n, h, w, cout, kh, kw, 1, dtype,
+                                    hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(yb.to_nchw(cout, 1).cpu(), _q(ref.relu(), dtype))
+    assert float(yb.data[:, :1].abs().max()) == 0 and float(yb.data[:, -1:].abs().max()) == 0
+    cap = n * h * ((w + 127) // 128) * cp * 2
+    stats = torch.full((cap,), float("nan"), device=gpu_device)
+    ntiles = ctypes.c_int(0)
+    y2 = hip.PlaneBuffer(n, hip.planes(cout, dtype), h, w, dtype, gpu_device, zero=True)
+    hip.check(hip.lib.dn_conv_first_stats(hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), y2.ref(cout), n, h, w, cout, kh, kw, dtype,
+                                          hip.ptr(stats), cap, ctypes.byref(ntiles), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    y = y2.to_nchw(cout).cpu()
+    assert torch.equal(y, _q(ref, dtype))
+    t = ntiles.value
+    assert 0 < t and t * cp * 2 <= cap
+    part = stats[:t * cp * 2].view(t, cp, 2).double().sum(0).cpu()
+    ysum, ysq = y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))
+    # per-tile partials are fp32 sums of numbers up to ~1e11: equal to the exact totals to fp32 rounding per tile
+    assert torch.allclose(part[:cout, 0], ysum, rtol=1e-6, atol=1.0) and torch.allclose(part[:cout, 1], ysq, rtol=1e-6, atol=1.0)
+    assert hip.lib.dn_conv_first_stats(hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), y2.ref(cout), n, h, w, cout, kh, kw, dtype,
+                                       hip.ptr(stats), 8, ctypes.byref(ntiles), hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 def test_maxpool_and_head(gpu_device, dtype):
     hip = _hip()
     n, c, h, w = 2, 40, 5, 64
