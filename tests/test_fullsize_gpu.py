@@ -135,3 +135,40 @@ def test_bn_backward_orthogonality_and_reproducibility(gpu_device):
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)                  # no atomics anywhere: bitwise reproducible
     assert float(runs[0][0].abs().max()) > 0 and bool(torch.isfinite(runs[0][0]).all())
+
+
+@pytest.mark.parametrize("cfg", [(4, (3, 5), 24, 3, 7, 256, 13), (4, (3, 5), 32, 5, 7, 512, 31)])
+def test_fp32_gradients_are_as_close_to_fp64_as_the_reference_arithmetic(gpu_device, cfg):
+    """Deep nets amplify fp32 round-off through 18 BatchNorms: against the oracle run in float64, this build's fp32
+    gradients must not be further away than the reference arithmetic (torch fp32) itself is -- that is what "within
+    tolerance of the reference" can mean for these tensors (scratch/diag_fp64.py prints the table)."""
+    from dnanet_amd.unet import HipUNet
+    from oracle import unet_oracle as O
+    depth, k, f, n, h, w, seed = cfg
+    torch.manual_seed(seed)
+    sd = O.init_state_dict(depth, k, f, seed=seed, randomize_bn_stats=True)
+    x = (torch.rand(n, 1, h, w) * 2000).round()
+    t = (torch.rand(n, 1, h, w) < 0.1).to(torch.int8)
+
+    def oracle(dt):
+        s = OrderedDict((kk, v.clone().to(dt) if v.is_floating_point() else v.clone()) for kk, v in sd.items())
+        return O.train_step(s, x.to(dt), t, O.AdamState(O.trainable_keys(s), s), 1e-3, 5e-4)
+
+    l32, _, g32 = oracle(torch.float32)
+    l64, _, g64 = oracle(torch.float64)
+    m = HipUNet(depth, k, f, gpu_device, dtype="fp32")
+    m.load_state_dict(sd)
+    m.train()
+    logits = m(x.to(gpu_device))
+    sums = m.dice_forward(logits, t.to(gpu_device))
+    m.backward()
+    assert abs(float(sums[4]) - float(l64)) < 1e-6
+    ours, theirs = [], []
+    for kk, g in g64.items():
+        if kk.endswith("double_conv.0.bias") or kk.endswith("double_conv.3.bias"):
+            continue                      # identically zero in exact arithmetic
+        nrm = float(g.norm()) + 1e-30
+        ours.append(float((m.grad(kk).cpu().double() - g).norm()) / nrm)
+        theirs.append(float((g32[kk].double() - g).norm()) / nrm)
+    assert max(ours) <= 2.0 * max(theirs) + 1e-5, (max(ours), max(theirs))
+    assert sorted(ours)[len(ours) // 2] <= 2.0 * sorted(theirs)[len(theirs) // 2] + 1e-5
