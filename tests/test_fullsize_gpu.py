@@ -25,7 +25,7 @@ def test_shipped_config_train_step_vs_oracle(gpu_device):
     state = O.AdamState(O.trainable_keys(ref_sd), ref_sd)
     ref_loss, ref_logits, ref_grads = O.train_step(ref_sd, x, t, state, 1e-4, 5e-4)
     # gtol bounds the worst single gradient element: at this size a handful of ReLU masks of near-zero activations flip
-    # with any change of summation order (3-5 % of the largest element for some seeds, scratch/diag_fullsize.py), while
+    # with any change of summation order (3-5 % of the largest element for some seeds, tests/tools/diag_fullsize.py), while
     # loss and logits agree to 1e-6 and every tensor's l2 error stays under 0.5 %
     for dtype, ltol, gtol in (("fp32", 1e-5, 8e-2), ("bf16", 2e-2, None)):
         m = HipUNet(4, (3, 5), 32, gpu_device, dtype=dtype)
@@ -141,7 +141,7 @@ def test_bn_backward_orthogonality_and_reproducibility(gpu_device):
 def test_fp32_gradients_are_as_close_to_fp64_as_the_reference_arithmetic(gpu_device, cfg):
     """Deep nets amplify fp32 round-off through 18 BatchNorms: against the oracle run in float64, this build's fp32
     gradients must not be further away than the reference arithmetic (torch fp32) itself is -- that is what "within
-    tolerance of the reference" can mean for these tensors (scratch/diag_fp64.py prints the table)."""
+    tolerance of the reference" can mean for these tensors (tests/tools/diag_fp64.py prints the table)."""
     from dnanet_amd.unet import HipUNet
     from oracle import unet_oracle as O
     depth, k, f, n, h, w, seed = cfg

@@ -1,5 +1,5 @@
 """Is the fp32 gradient deviation round-off?  HIP fp32 and the fp32 oracle are both compared with the oracle in fp64."""
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from collections import OrderedDict
 import torch
 from dnanet_amd.unet import HipUNet

@@ -1,5 +1,5 @@
 """One-off: whole-net inference + one training step against the oracle on random small configurations (fp32 mode)."""
-import os, sys, random; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys, random; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from collections import OrderedDict
 import torch
 from dnanet_amd.unet import HipAdam, HipUNet
