@@ -29,6 +29,32 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def predict_batch_sharded(model, images: Sequence, group=None, dst: int = 0):
+    """``model.predict_batch`` over one node's GPUs (inference): every rank predicts its contiguous shard of
+    ``images`` -- allele calling included, so only a few hundred bytes of calls plus the probability map per profile
+    leave the rank -- and rank ``dst`` receives the complete list in the order of ``images`` (the other ranks get None).
+    No collective on the data path; the ordered gather is one ``gather_object`` (use a gloo group for it: the payload
+    is host objects)."""
+    images = list(images)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    start, stop = shard_range(len(images), rank, world)
+    local = list(model.predict_batch(images[start:stop])) if stop > start else []
+    for p in local:                       # the device pixel counts are tagged with this rank's image objects
+        tag = getattr(p, "_pixel_counts", None)
+        if tag is not None:
+            p._pixel_counts = (None,) + tuple(tag[1:])
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(local, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = [p for part in parts for p in part]
+    for image, p in zip(images, out):
+        tag = getattr(p, "_pixel_counts", None)
+        if tag is not None:
+            p._pixel_counts = (id(image),) + tuple(tag[1:])
+    return out
+
+
 def module_segments(offsets: Dict[str, tuple], depth: int, total: Optional[int] = None) -> List[Tuple[str, int, int]]:
     """Arena ranges [(segment name, start, stop)] of the trainable parameters per top-level module,
     in the order the backward pass completes them.  Ranges tile the arena (alignment padding included)."""

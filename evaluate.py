@@ -12,6 +12,11 @@ from dnanet_amd.config_io import dump_config, load_dataset, load_evaluation_conf
 
 def run(data_config, model_config, evaluation_config=None, output_dir=None, checkpoint_dir=None, save_preds=False,
         split=None, seed=None):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                   # one rank per GPU: pick it before the model is built on "cuda"
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     output_dir = start_run("evaluate", output_dir, "log_evaluation.txt")
     LOGGER.info("Loading model...")
     model = load_model(model_config)
@@ -24,7 +29,17 @@ def run(data_config, model_config, evaluation_config=None, output_dir=None, chec
         LOGGER.info("Splitting dataset, using %s%% for evaluation", split * 100)
         _, dataset = dataset.split(1 - split, seed=seed)
     LOGGER.info("Applying model...")
-    predictions = model.predict_batch(dataset)
+    if world > 1:
+        # launched with torch.distributed.run: every rank predicts its shard, rank 0 scores
+        import torch.distributed as dist
+        from dnanet_amd.distributed import predict_batch_sharded
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")       # the only exchange is the ordered gather of host objects
+        predictions = predict_batch_sharded(model, dataset)
+        if dist.get_rank() != 0:
+            return {}
+    else:
+        predictions = model.predict_batch(dataset)
     results = {}
     if evaluation_config:
         LOGGER.info("Computing metrics...")

@@ -74,3 +74,51 @@ def test_bucketed_all_reduce_gloo_world2():
     for rank, ok_sum, ok_cover, nb, ok_dice in res:
         assert ok_sum and ok_cover and ok_dice, (rank, ok_sum, ok_cover, ok_dice)
         assert 1 < nb < 6          # a handful of buckets, not one per tensor
+
+
+def _sharded_predict_worker(rank, world, port, out_path):
+    import os
+    import numpy as np
+    import torch.distributed as dist
+    from dnanet_amd.distributed import predict_batch_sharded
+    from dnanet_amd.prediction import Prediction
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Image:
+        def __init__(self, i):
+            self.path, self.value = f"p{i}", i
+
+    class Stub:                                    # stands in for DNANet_UNet.predict_batch (which needs the GPU)
+        def predict_batch(self, batch):
+            preds = [Prediction(image=np.full((1, 2, 1), im.value, np.float32), meta={"original_image_path": im.path,
+                                                                                        "rank": rank}) for im in batch]
+            for im, p in zip(batch, preds):
+                p._pixel_counts = (id(im), 0.5, (im.value, 0, 0, 0, 0, 0))
+            return preds
+
+    images = [Image(i) for i in range(7)]
+    got = predict_batch_sharded(Stub(), images)
+    if rank == 0:
+        assert [p.meta["original_image_path"] for p in got] == [f"p{i}" for i in range(7)]
+        assert [p.meta["rank"] for p in got] == [0, 0, 0, 0, 1, 1, 1]
+        assert all(float(p.image[0, 0, 0]) == i for i, p in enumerate(got))
+        assert all(p._pixel_counts[0] == id(im) and p._pixel_counts[2][0] == i for i, (im, p) in enumerate(zip(images, got)))
+        open(out_path, "w").write("ok")
+    else:
+        assert got is None
+    empty = predict_batch_sharded(Stub(), images[:1])          # fewer images than ranks: rank 1's shard is empty
+    assert (len(empty) == 1) if rank == 0 else empty is None
+    dist.destroy_process_group()
+
+
+def test_predict_batch_sharded_gloo_world2(tmp_path):
+    """Inference shards by profile: contiguous shards, ordered gather on rank 0, no other exchange."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "ok.txt"
+    mp.spawn(_sharded_predict_worker, args=(2, port, str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
