@@ -160,6 +160,13 @@ class DNANet_UNet(TrainableModel):
         self.allele_caller = NearestBasePairCaller() if apply_allele_caller else None
         self._resident: Optional[_ResidentSet] = None
         self._graph = {"enabled": False, "step": None, "warm": False}
+        self._dp = None
+
+    @staticmethod
+    def _group_size() -> int:
+        """Ranks of the default process group, 0 when there is none."""
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 0
 
     # ---- tensorisation (trainable_unet.py:60-89) ---------------------------------------------------
     @staticmethod
@@ -261,9 +268,24 @@ class DNANet_UNet(TrainableModel):
         self.make_resident(dataset, validation_set)
         # Small batches are bound by the host issuing ~330 launches per step: replay them from a HIP graph
         # (``hip_graph=True/False`` overrides; large batches gain nothing and would pin their activations).
+        # Data parallel: when the process runs inside an initialised torch.distributed group of more than
+        # one rank (train.py under torch.distributed.run), ``batch_size`` is the GLOBAL batch; every rank takes its
+        # slice of each batch, the Dice sums and the gradient arena are all-reduced (``DataParallelTrainer``).
+        # ``data_parallel=True`` forces that path in a group of one (tests), ``False`` switches it off.
+        dp = kwargs.pop("data_parallel", None)
+        group_size = self._group_size()
+        if dp is None:
+            dp = group_size > 1
+        if dp and group_size < 1:
+            raise RuntimeError("data_parallel=True needs an initialised torch.distributed process group")
+        if dp and batch_size % group_size:
+            raise ValueError(f"batch_size {batch_size} is not divisible by the {group_size} ranks of the process group")
+        self._dp = {"trainer": None} if dp else None
         use_graph = kwargs.pop("hip_graph", None)
         if use_graph is None:
-            use_graph = batch_size <= 64
+            use_graph = batch_size <= 64 and not dp
+        if use_graph and dp:
+            raise ValueError("hip_graph and data_parallel exclude each other (the all-reduce is not captured)")
         self._graph = {"enabled": bool(use_graph) and self._model.device.type == "cuda", "step": None, "warm": False,
                        "batch_size": batch_size}
         try:
@@ -272,11 +294,18 @@ class DNANet_UNet(TrainableModel):
         finally:
             self.release_resident()
             self._graph = {"enabled": False, "step": None, "warm": False}
+            self._dp = None
         if writer:
             writer.close()
         if save_best:
             self.load(checkpoint_dir / "best_model")
-            shutil.rmtree(checkpoint_dir / "best_model")
+            if self._group_size() > 1:                 # every rank has read it before rank 0 removes it
+                import torch.distributed as dist
+                dist.barrier()
+                if dist.get_rank() == 0:
+                    shutil.rmtree(checkpoint_dir / "best_model")
+            else:
+                shutil.rmtree(checkpoint_dir / "best_model")
             LOGGER.info("Restored previous best model")
 
     def _fit_epochs(self, dataset, validation_set, num_epochs, steps_per_epoch, steps_per_epoch_val, batch_size, optimizer,
@@ -345,7 +374,11 @@ class DNANet_UNet(TrainableModel):
         epoch_loss = 0.
         pending = None       # the loss of step k is read back after step k+1 is queued: the GPU never waits for the host
         for step, batch in enumerate(batches):
-            loss = self._graphed_train_step(batch, metrics, optimizer) if train else None
+            loss = None
+            if train and self._dp is not None:
+                loss = self._data_parallel_step(batch, metrics, optimizer)
+            elif train:
+                loss = self._graphed_train_step(batch, metrics, optimizer)
             if loss is None:
                 loss = self.step(batch, metrics)
                 if train:
@@ -359,7 +392,30 @@ class DNANet_UNet(TrainableModel):
             pending, last = loss, step
         if pending is not None:
             epoch_loss = (epoch_loss * last + float(pending)) / (last + 1)
+        if train and self._dp is not None:
+            # BatchNorm running statistics are per replica: continue from rank 0's, so that validation losses -- and with
+            # them early stopping and best-model decisions -- are identical on every rank
+            import torch.distributed as dist
+            dist.broadcast(self._model.flat_stats, src=0)
+            self._model._param_epoch += 1
         return epoch_loss
+
+    def _data_parallel_step(self, batch: Sequence, metrics, optimizer: HipAdam) -> Optional[_Loss]:
+        """This rank's slice of a global batch through ``DataParallelTrainer.step`` (forward, all-reduced Dice sums,
+        backward with bucketed gradient all-reduce, Adam).  A short last batch (validation-style) is not sliced."""
+        import torch.distributed as dist
+        from .distributed import DataParallelTrainer
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if len(batch) % world:
+            raise ValueError(f"a batch of {len(batch)} profiles cannot be split over {world} ranks")
+        per = len(batch) // world
+        local = batch[rank * per:(rank + 1) * per]
+        cfg = self._dp
+        if cfg["trainer"] is None or cfg["trainer"].optimizer is not optimizer:
+            cfg["trainer"] = DataParallelTrainer(self._model, optimizer)
+        inputs, y_true = self.get_inputs(local), self.get_targets(local)
+        sums = cfg["trainer"].step(inputs, y_true)
+        return _Loss(self._model, sums, inputs.numel() * world, metrics)
 
     def _graphed_train_step(self, batch: Sequence, metrics, optimizer: HipAdam) -> Optional[_Loss]:
         """step + backward + optimizer.step + zero_grad as one HIP-graph replay; None when this batch has to take the
@@ -472,6 +528,17 @@ class DNANet_UNet(TrainableModel):
 
     # ---- checkpoints (trainable_unet.py:447-470) -------------------------------------------------------
     def save(self, model_dir):
+        """Inside a process group only rank 0 writes (the replicas hold the same parameters); everybody waits for it."""
+        ranks = self._group_size()
+        if ranks > 1:
+            import torch.distributed as dist
+            if dist.get_rank() == 0:
+                self._save(model_dir)
+            dist.barrier()
+        else:
+            self._save(model_dir)
+
+    def _save(self, model_dir):
         os.makedirs(model_dir, exist_ok=True)
         state = {k: v.detach().cpu().clone() for k, v in self._model.state_dict().items()}
         torch.save(state, self._get_weights_path(model_dir))

@@ -149,6 +149,44 @@ def test_data_parallel_step_world1_equals_plain_step(gpu_device):
         dist.destroy_process_group()
 
 
+def test_fit_data_parallel_world1_equals_plain_fit(gpu_device, tmp_path):
+    """fit() inside a process group (here one rank, forced with data_parallel=True): the slice / all-reduce / broadcast
+    path -- with a validation set, save_best and the scheduler -- gives the parameters, statistics and checkpoint of
+    the plain loop; a global batch that the ranks cannot share is refused."""
+    import torch.distributed as dist
+    from dnanet_amd.model import DNANet_UNet
+    from dnanet_amd.synthetic import make_batch
+    x, t = make_batch(10, 5, 256, seed=12, unique=10)
+    images = _images(x, t)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    states = []
+    for dp in (False, True):
+        torch.manual_seed(0)
+        model = DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False)
+        if dp:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+        try:
+            ckpt = tmp_path / f"dp{int(dp)}"
+            model.fit(images[:8], batch_size=4, num_epochs=3, learning_rate=2e-3, validation_set=images[8:], min_delta=-99999,
+                      checkpoint_dir=str(ckpt), save_best=True, use_scheduler=True, hip_graph=False,
+                      **({"data_parallel": True} if dp else {}))
+            model.save(str(ckpt))
+            assert os.path.exists(ckpt / "DNANet_UNet_checkpoint.pt") and not os.path.exists(ckpt / "best_model")
+            if dp:
+                with pytest.raises(ValueError):
+                    model.fit(images[:8], batch_size=4, num_epochs=1, hip_graph=True, data_parallel=True)
+        finally:
+            if dp:
+                dist.destroy_process_group()
+        states.append({k: v.detach().cpu().clone() for k, v in model._model.state_dict().items()})
+    for k, v in states[0].items():
+        assert torch.equal(states[1][k], v), k
+    with pytest.raises(RuntimeError):
+        DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False).fit(images[:4], batch_size=4, num_epochs=1,
+                                                                                data_parallel=True)
+
+
 def test_resident_dataset_batches_equal_per_step_tensorisation(gpu_device):
     """Input pipeline: batches gathered from the HBM-resident copy are the tensors get_inputs /
     get_targets build from the images themselves -- in dataset order (a view), shuffled (a gather), and a batch

@@ -4,6 +4,7 @@ Same flags and order of operations as the reference's ``train.py`` (load model, 
 dataset, ``fit``, ``save``, dump the config next to the weights); runs on ``dnanet_amd``.
 """
 import argparse
+import os
 
 from dnanet_amd.cli import LOGGER, split_validation, start_run
 from dnanet_amd.config_io import dump_config, load_dataset, load_model, load_training_config
@@ -12,6 +13,20 @@ from dnanet_amd.model import TrainableModel
 
 def run(data_config, model_config, training_config, split=None, output_dir=None, validation_config=None,
         checkpoint_dir=None, seed=None):
+    # Under torch.distributed.run (one rank per GPU) fit() trains data parallel: `batch_size` of the training config is the
+    # global batch, gradients are all-reduced over RCCL, rank 0 writes the outputs (not in the reference).
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        if not output_dir:                              # the default name carries a timestamp: rank 0 picks it
+            from datetime import datetime
+            box = [os.path.join("output", f"train_{datetime.now().strftime('%Y-%m-%d_%H-%M-%S')}")]
+            dist.broadcast_object_list(box, src=0)
+            output_dir = box[0]
     output_dir = start_run("train", output_dir, "log_training.txt")
     LOGGER.info("Loading model...")
     model = load_model(model_config)
@@ -39,7 +54,8 @@ def run(data_config, model_config, training_config, split=None, output_dir=None,
         LOGGER.info("Training interrupted!")
     model.save(output_dir)
     LOGGER.info("Saved model to %s", output_dir)
-    dump_config(f"{output_dir}/config.yaml", data_config, model_config, training_config, validation_config, dataset, model)
+    if rank == 0:
+        dump_config(f"{output_dir}/config.yaml", data_config, model_config, training_config, validation_config, dataset, model)
     return output_dir
 
 
