@@ -2,7 +2,7 @@ import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from dnanet_amd import hip
 dev = torch.device('cuda:0')
-n, h = 256, 5
+n, h = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dtype = hip.BF16
 for cin, cout, win in [(512, 512, 256), (256, 256, 512), (64, 64, 2048)]:
     x = hip.PlaneBuffer(n, hip.planes(cin, dtype), h, win, dtype, dev); x.data.normal_()
