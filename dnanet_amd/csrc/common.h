@@ -42,6 +42,16 @@ int dn_set_error(int code, const char* fmt, ...);
   return dn_set_error(DN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
 #define DN_LAUNCH_CHECK() DN_CHECK_HIP(hipGetLastError())
 
+// Sum over the 16 lanes of a DPP row, result in every lane of the row: four VALU adds with DPP operands (quad_perm
+// [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8) instead of four trips through the LDS crossbar (__shfl_xor = ds_bpermute).
+__device__ __forceinline__ float dn_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return v;
+}
+
 // ---- LDS-DMA with buffer addressing (gfx950: buffer_load_dwordx4 ... lds)
 // Written as inline asm on purpose: hipcc neither drains nor counts it, so loads stay in flight across the ds_reads of
 // the tile being consumed and are waited for by hand (s_waitcnt vmcnt).  Buffer addressing keeps the per-piece VALU

@@ -221,12 +221,13 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
       }
     }
     if constexpr (STATS) {
-      // sum over the 32 pixel lanes of each half-wave (xor masks < 32 stay inside a half), lane 0 / 32 keeps the totals
+      // sum over the 32 pixel lanes of each half-wave: DPP adds inside each row of 16 lanes, one exchange between the two
+      // rows of the half; lane 0 / 32 keeps the totals
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float a = ssum[r], b = ssq[r];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+        float a = dn_row16_sum(ssum[r]), b = dn_row16_sum(ssq[r]);
+        a += __shfl_xor(a, 16);
+        b += __shfl_xor(b, 16);
         if (l31 == 0) {
           const int ch = ps * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
           stat_wave[ch * 2] = a;
