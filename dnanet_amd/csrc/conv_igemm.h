@@ -121,20 +121,26 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
                                                     int cot, int lane) {
   constexpr bool STATS = EPI == CONV_EPI_STATS, POOL = EPI == CONV_EPI_POOL;
   constexpr int NCG = COT / 32, EPR = RecTraits<T>::EPR, GPL = 32 / EPR;
-  constexpr int NPASS = STATS ? NCG : 1, CPP = NCG / NPASS;        // passes over the rows, channel groups per pass
+  // where the statistics are accumulated: inside the store loop (16 + 16 live sums per lane, hence one pass per channel
+  // group), or -- for the 3-row x 64-channel tile, where those 40 registers cost the third workgroup per CU (+160..240 us
+  // per layer) -- in a second walk over the accumulators, four channels at a time, after the plain store loop
+  constexpr bool STATS_WALK2 = STATS && HT == 3 && COT == 64;
+  constexpr bool STATS_INLOOP = STATS && !STATS_WALK2;
+  constexpr int NPASS = STATS_INLOOP ? NCG : 1, CPP = NCG / NPASS;  // passes over the rows, channel groups per pass
   const int l31 = lane & 31, half = lane >> 5;
   unsigned char* yb = (unsigned char*)p.y;
   const int yrow = p.W * p.y_wmul;
   const bool col_ok = wbase + l31 < p.W;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
+    float ssum[STATS_INLOOP ? 16 : 1] = {}, ssq[STATS_INLOOP ? 16 : 1] = {};
+    (void)ssum; (void)ssq;
     float bias_r[CPP][16];
 #pragma unroll
     for (int c = 0; c < CPP; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         bias_r[c][r] = p.bias ? p.bias[cot * COT + (ps * CPP + c) * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
-    float ssum[STATS ? 16 : 1] = {}, ssq[STATS ? 16 : 1] = {};
 #pragma unroll
     for (int hh = 0; hh < HT; ++hh) {
       const int h = h0 + hh;
@@ -159,12 +165,12 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
               u.x = (uint32_t)__builtin_bit_cast(unsigned short, bq[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[1]) << 16);
               u.y = (uint32_t)__builtin_bit_cast(unsigned short, bq[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[3]) << 16);
               *(uint2*)dst = u;
-              if constexpr (STATS) {
+              if constexpr (STATS_INLOOP) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = (float)bq[i];     // statistics of the values as stored
               }
             }
-            if constexpr (STATS) {
+            if constexpr (STATS_INLOOP) {
               if (col_ok) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { ssum[4 * g + i] += v[i]; ssq[4 * g + i] = fmaf(v[i], v[i], ssq[4 * g + i]); }
@@ -221,17 +227,43 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
       }
     }
     if constexpr (STATS) {
-      // sum over the 32 pixel lanes of each half-wave: DPP adds inside each row of 16 lanes, one exchange between the two
-      // rows of the half; lane 0 / 32 keeps the totals
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = dn_row16_sum(ssum[r]), b = dn_row16_sum(ssq[r]);
+      // Sum over the 32 pixel lanes of each half-wave: DPP adds inside each row of 16 lanes, one exchange between the
+      // two rows of the half; lane 0 / 32 keeps the totals.
+      auto publish = [&](int cgi, int r, float a, float b) {
+        a = dn_row16_sum(a); b = dn_row16_sum(b);
         a += __shfl_xor(a, 16);
         b += __shfl_xor(b, 16);
         if (l31 == 0) {
-          const int ch = ps * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+          const int ch = cgi * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
           stat_wave[ch * 2] = a;
           stat_wave[ch * 2 + 1] = b;
+        }
+      };
+      if constexpr (STATS_INLOOP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) publish(ps, r, ssum[r], ssq[r]);
+      } else {
+#pragma unroll
+       for (int c = 0; c < CPP; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int hh = 0; hh < HT; ++hh) {
+            if (h0 + hh < p.H) {                      // block-uniform
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float v = acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if constexpr (sizeof(T) == 2) v = (float)(__bf16)v;     // statistics of the values as stored
+                v = col_ok ? v : 0.f;
+                s4[i] += v;
+                q4[i] = fmaf(v, v, q4[i]);
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) publish(ps * CPP + c, 4 * g + i, s4[i], q4[i]);
         }
       }
     }
