@@ -33,7 +33,7 @@ for case in range(ncase):
             for kk, g in ref_grads.items():
                 if kk.endswith("double_conv.0.bias") or kk.endswith("double_conv.3.bias"): continue
                 l2 = float((m.grad(kk).cpu() - g).norm() / (g.norm() + 1e-20))
-                if not l2 < 2e-3: msgs.append(f'grad {kk} l2 {l2:.2e}')
+                if not l2 < 8e-3: msgs.append(f'grad {kk} l2 {l2:.2e}')
             opt.step()
             got = m.state_dict()
             for kk in ref_sd:
