@@ -164,6 +164,39 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const unsigned char*
   }
 }
 
+// The same pass for an encoder block's second unit, with MaxPool2d((1,2)) of the activation written alongside
+// (unet_architecture.py:37): a thread handles the same channel piece of the two pixels of a pooling pair.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_relu_pool_kernel(const unsigned char* y, int y_pt, int y_p0, unsigned char* a,
+                                                                 int a_pt, int a_p0, unsigned char* pooled, int p_pt, int p_p0,
+                                                                 int npieces, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift) {
+  constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const unsigned char* yp = y + ((long)n * y_pt + y_p0 + pl) * npieces * 16;
+  unsigned char* ap = a + ((long)n * a_pt + a_p0 + pl) * npieces * 16;
+  unsigned char* pp = pooled + ((long)n * p_pt + p_p0 + pl) * (npieces / 2) * 16;
+  const int c0 = pl * EPR + (threadIdx.x & 1) * PN;       // even stride: the piece parity = the channels stay with the thread
+  float sc[PN], sh[PN];
+#pragma unroll
+  for (int j = 0; j < PN; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npieces / 2; k += gridDim.x * blockDim.x) {
+    const long i0 = (long)(k >> 1) * 4 + (k & 1);         // pieces of pixel 2j and (i0 + 2) of pixel 2j + 1
+    float f0[PN], f1[PN], m[PN];
+    Piece<T>::unpack(*(const uint4*)(yp + i0 * 16), f0);
+    Piece<T>::unpack(*(const uint4*)(yp + (i0 + 2) * 16), f1);
+#pragma unroll
+    for (int j = 0; j < PN; ++j) {
+      f0[j] = fmaxf(fmaf(f0[j], sc[j], sh[j]), 0.f);
+      f1[j] = fmaxf(fmaf(f1[j], sc[j], sh[j]), 0.f);
+      m[j] = fmaxf(f0[j], f1[j]);                         // rounding is monotonic: max of the stored values
+    }
+    *(uint4*)(ap + i0 * 16) = Piece<T>::pack(f0);
+    *(uint4*)(ap + (i0 + 2) * 16) = Piece<T>::pack(f1);
+    *(uint4*)(pp + (long)k * 16) = Piece<T>::pack(m);
+  }
+}
+
 // ---- BatchNorm backward ------------------------------------------------------------------------
 // reduce: S1 = sum(dz), S2 = sum(dz * xhat), dz = g * (y*scale + shift > 0), xhat = (y - mean) * invstd.
 // The ReLU mask is recomputed from y with the forward's fused scale / shift (the same fmaf the apply pass rounded to get
@@ -514,7 +547,8 @@ int dn_reduce_blocks(long pixels) { return red_blocks(pixels); }
 
 static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                                 float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream);
+                                 float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream,
+                                 const dn_tensor* pooled = nullptr);
 
 int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
@@ -531,10 +565,19 @@ int dn_bn_train_apply(dn_tensor y, dn_tensor a, int N, int H, int W, const float
                                (float*)partial, ntiles, dtype, stream);
 }
 
+int dn_bn_train_apply_pool(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, int H, int W, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                           float* scale, float* shift, const float* partial, int ntiles, int dtype, void* stream) {
+  DN_CHECK_ARG(ntiles > 0, "dn_bn_train_apply_pool: no partial statistics");
+  return bn_train_forward_impl(y, a, N, H, W, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                               (float*)partial, ntiles, dtype, stream, &pooled);
+}
+
 // given_nblk > 0: `partial` already holds [given_nblk][cpad][2] sums (dn_conv2d_stats), the statistics pass is skipped
 static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                                 float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream) {
+                                 float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream,
+                                 const dn_tensor* pooled) {
   DN_CHECK_ARG(y.base && a.base && gamma && beta && mean && invstd && scale && shift && partial, "dn_bn_train_forward: null pointer");
   DN_CHECK_ARG(y.channels == a.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_forward: bad shape");
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
@@ -554,6 +597,19 @@ static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, 
   DN_LAUNCH_CHECK();
   const int npieces = (int)(HW * 2);
   const dim3 egrid(std::min((npieces + 1023) / 1024, 64), nplanes, N);   // ~4 pieces per thread
+  if (pooled) {
+    DN_CHECK_ARG(W % 2 == 0 && pooled->base && pooled->channels == C && pooled->plane0 >= 0 &&
+                 pooled->plane0 + nplanes <= pooled->planes_total, "dn_bn_train_apply_pool: bad pooled tensor (W must be even)");
+#define ARGS_P (const unsigned char*)y.base, y.planes_total, y.plane0, (unsigned char*)a.base, a.planes_total, a.plane0, \
+               (unsigned char*)pooled->base, pooled->planes_total, pooled->plane0, npieces, scale, shift
+    DN_DISPATCH_T(dtype,
+      hipLaunchKernelGGL(bn_apply_relu_pool_kernel<__bf16>, egrid, dim3(256), 0, s, ARGS_P),
+      hipLaunchKernelGGL(bn_apply_relu_pool_kernel<float>, egrid, dim3(256), 0, s, ARGS_P),
+      "dn_bn_train_apply_pool");
+#undef ARGS_P
+    DN_LAUNCH_CHECK();
+    return DN_OK;
+  }
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(bn_apply_relu_kernel<__bf16>, egrid, dim3(256), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (unsigned char*)a.base, a.planes_total, a.plane0, npieces, scale, shift),
     hipLaunchKernelGGL(bn_apply_relu_kernel<float>, egrid, dim3(256), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, (unsigned char*)a.base, a.planes_total, a.plane0, npieces, scale, shift),

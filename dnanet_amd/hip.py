@@ -82,6 +82,8 @@ _SIGS = {
     "dn_conv2d_stats": (c_int, [DnTensor, _P, _P, DnTensor, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, POINTER(c_int), _P]),
     "dn_bn_train_apply": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
                                   c_int, c_int, _P]),
+    "dn_bn_train_apply_pool": (c_int, [DnTensor, DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
+                                  c_int, c_int, _P]),
     "dn_call_alleles": (c_int, [_P, _P, _P, c_long, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
 }
 

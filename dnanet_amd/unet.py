@@ -333,8 +333,9 @@ class HipUNet(ParameterTree):
                 entry["w"], entry["wd"] = self._pack(wv, None, hip.PACK_FWD), self._pack(wv, None, hip.PACK_DGRAD)
         self._train_cache_version = self._versions()
 
-    def _unit_forward(self, u: ConvUnit, src, dst, n, h, w, raw_x=None):
-        """conv + bias -> y ; batch-stat BatchNorm + ReLU -> dst.  Saves what backward needs."""
+    def _unit_forward(self, u: ConvUnit, src, dst, n, h, w, raw_x=None, pooled=None):
+        """conv + bias -> y ; batch-stat BatchNorm + ReLU -> dst (and MaxPool2d((1,2)) of it -> pooled).  Saves what
+        backward needs."""
         ws, cache = self._workspace(), self._train_cache
         y = PlaneBuffer(n, self._pp(u.cout), h, w, self.dtype, self.device)
         cp = hip.channel_pad(u.cout)
@@ -360,12 +361,18 @@ class HipUNet(ParameterTree):
                 hip.check(hip.lib.dn_conv2d_stats(src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, kh, kw,
                                                   self.dtype, hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles),
                                                   hip.stream_ptr()))
-            hip.check(hip.lib.dn_bn_train_apply(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["bnstat"]), ntiles.value,
-                                                self.dtype, hip.stream_ptr()))
+            if pooled is not None:
+                hip.check(hip.lib.dn_bn_train_apply_pool(y.ref(u.cout), dst, pooled, n, h, w, *bn_args, hip.ptr(ws["bnstat"]),
+                                                         ntiles.value, self.dtype, hip.stream_ptr()))
+            else:
+                hip.check(hip.lib.dn_bn_train_apply(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["bnstat"]), ntiles.value,
+                                                    self.dtype, hip.stream_ptr()))
         else:
             self._conv(u, cache[u.conv], raw_x if u.cin == 1 else src, y.ref(u.cout), n, h, w, relu=0)
             hip.check(hip.lib.dn_bn_train_forward(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["partial"]), self.dtype,
                                                   hip.stream_ptr()))
+            if pooled is not None:
+                hip.check(hip.lib.dn_maxpool_1x2(dst, pooled, n, h, w // 2, self.dtype, hip.stream_ptr()))
         self._saved[u.conv] = {"y": y, "a": dst, "src": src, "mean": mean, "invstd": invstd, "scale": scale, "shift": shift,
                                "vec": vec, "n": n, "h": h, "w": w}
 
@@ -389,9 +396,8 @@ class HipUNet(ParameterTree):
             a1 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
             self._unit_forward(units[pre + ".0"], None if l == 0 else cur, a1.ref(c[l]), n, h, ws[l], raw_x=x)
             skip = cat[l].ref(c[l], self._pp(c[l]))
-            self._unit_forward(units[pre + ".3"], a1.ref(c[l]), skip, n, h, ws[l])
             pooled = PlaneBuffer(n, self._pp(c[l]), h, ws[l + 1], dt, dev)
-            hip.check(hip.lib.dn_maxpool_1x2(skip, pooled.ref(c[l]), n, h, ws[l + 1], dt, hip.stream_ptr()))
+            self._unit_forward(units[pre + ".3"], a1.ref(c[l]), skip, n, h, ws[l], pooled=pooled.ref(c[l]))
             S[f"pooled{l}"] = pooled
             cur = pooled.ref(c[l])
         pre = "bottleneck.double_conv"

@@ -149,6 +149,11 @@ int dn_conv2d_stats(dn_tensor x, const void* packed_w, const float* bias, dn_ten
 int dn_bn_train_apply(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                       float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                       float* scale, float* shift, const float* partial, int ntiles, int dtype, void* stream);
+/* dn_bn_train_apply for the second unit of an encoder block: also writes MaxPool2d((1,2)) of the activation
+ * (unet_architecture.py:37) into `pooled` (W/2 columns), saving the pooling pass over a. */
+int dn_bn_train_apply_pool(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, int H, int W, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                           float* scale, float* shift, const float* partial, int ntiles, int dtype, void* stream);
 /* Backward of ReLU + BatchNorm2d (autograd of the above, trainable_unet.py:342): on entry g = dL/da,
  * on exit g = dL/dy (in place); dgamma/dbeta are written ([C]); coef: 3*dn_channel_pad(C) scratch.
  * scale/shift/mean/invstd are the vectors dn_bn_train_forward saved: the ReLU mask is recomputed as

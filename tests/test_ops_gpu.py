@@ -507,6 +507,51 @@ def test_batchnorm_train_forward_backward(gpu_device, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+def test_bn_apply_from_tile_statistics_with_pool(gpu_device, dtype):
+    """dn_bn_train_apply / dn_bn_train_apply_pool from per-tile (sum, sum of squares) partials: the activation equals
+    dn_bn_train_forward's bit for bit when the partials add up to the same statistics, and the pooled output is
+    MaxPool2d((1,2)) of that activation."""
+    hip = _hip()
+    n, c, h, w = 3, 40, 5, 96
+    dev = gpu_device
+    g = torch.Generator().manual_seed(6)
+    y = torch.randint(-8, 9, (n, c, h, w), generator=g).float()       # integers: every partition of the sums is exact
+    yb = hip.PlaneBuffer.from_nchw(y.to(dev), dtype)
+    cp = hip.channel_pad(c)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+
+    def run(fn, *extra):
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        vec = torch.zeros(4 * cp, device=dev)
+        ab = hip.PlaneBuffer(n, hip.planes(c, dtype), h, w, dtype, dev, zero=True)
+        args = [yb.ref(c), ab.ref(c)] + ([extra[0]] if extra[0] is not None else []) + [n, h, w, hip.ptr(gd), hip.ptr(bd), hip.ptr(rm), hip.ptr(rv), 0.1, 1e-5] + \
+               [hip.ptr(vec[i * cp:(i + 1) * cp]) for i in range(4)] + list(extra[1:]) + [dtype, hip.stream_ptr()]
+        hip.check(fn(*args))
+        torch.cuda.synchronize()
+        return ab.to_nchw(c).cpu(), rm.cpu(), rv.cpu()
+
+    gd, bd = gamma.to(dev), beta.to(dev)
+    part = torch.empty(hip.partial_floats(c), device=dev)
+    a_ref, rm_ref, rv_ref = run(hip.lib.dn_bn_train_forward, None, hip.ptr(part))
+    # two "tiles" per image row pair: sums over disjoint pixel sets, laid out [tile][cpad][2]
+    tiles = []
+    for img in range(n):
+        for half in (slice(0, w // 2), slice(w // 2, w)):
+            blk = y[img, :, :, half].double()
+            t = torch.zeros(cp, 2)
+            t[:c, 0], t[:c, 1] = blk.sum((1, 2)), (blk ** 2).sum((1, 2))
+            tiles.append(t)
+    tile_part = torch.stack(tiles).float().to(dev)
+    a1, rm1, rv1 = run(hip.lib.dn_bn_train_apply, None, hip.ptr(tile_part), len(tiles))
+    assert torch.equal(a1, a_ref) and torch.equal(rm1, rm_ref) and torch.equal(rv1, rv_ref)
+    pb = hip.PlaneBuffer(n, hip.planes(c, dtype) + 2, h, w // 2, dtype, dev, zero=True)
+    a2, _, _ = run(hip.lib.dn_bn_train_apply_pool, pb.ref(c, 1), hip.ptr(tile_part), len(tiles))
+    assert torch.equal(a2, a_ref)
+    assert torch.equal(pb.to_nchw(c, 1).cpu(), F.max_pool2d(a_ref, (1, 2)))
+    assert float(pb.data[:, :1].abs().max()) == 0 and float(pb.data[:, -1:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 def test_maxpool_backward_with_skip(gpu_device, dtype):
     hip = _hip()
     n, c, h, w = 2, 24, 5, 64
