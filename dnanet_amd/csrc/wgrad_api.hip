@@ -27,17 +27,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       if (k < 2 && c < Cout && ci < Cin) dst = ((long)ci * Cout + c) * 2 + k;
     }
     if (dst < 0) continue;
-    // many slabs (small tensors): four independent chains keep loads in flight; fixed order => reproducible
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // many slabs (small tensors, few threads): eight independent chains keep loads in flight; fixed order => reproducible
+    float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int b = 0;
-    for (; b + 3 < nslab; b += 4) {
-      s0 += slab[(long)b * per + i];
-      s1 += slab[(long)(b + 1) * per + i];
-      s2 += slab[(long)(b + 2) * per + i];
-      s3 += slab[(long)(b + 3) * per + i];
+    for (; b + 7 < nslab; b += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] += slab[(long)(b + k) * per + i];
     }
-    for (; b < nslab; ++b) s0 += slab[(long)b * per + i];
-    dw[dst] = (s0 + s1) + (s2 + s3);
+    for (; b < nslab; ++b) c[0] += slab[(long)b * per + i];
+    dw[dst] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
   }
 }
 
@@ -55,7 +53,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_conv_kernel(const float* __r
     float s = 0.f;
     if (ci0 + cil < ci_pad) {
       const float* src = slab + ((long)tap * co_pad + co) * ci_pad + ci0 + cil;
-      for (int b = 0; b < nslab; ++b) s += src[(long)b * per];
+      // four independent chains keep the slab loads in flight (a single chain is one load latency per slab); fixed order
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int b = 0;
+      for (; b + 3 < nslab; b += 4) {
+        s0 += src[(long)b * per];
+        s1 += src[(long)(b + 1) * per];
+        s2 += src[(long)(b + 2) * per];
+        s3 += src[(long)(b + 3) * per];
+      }
+      for (; b < nslab; ++b) s0 += src[(long)b * per];
+      s = (s0 + s1) + (s2 + s3);
     }
     tile[tap * 64 + cil] = s;
   }
