@@ -3,23 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one eval-mode pass of the shipped U-Net (depth 4, kernel (3,5), 32 filters,
-config/models/unet.yaml) over one batch of 256 synthetic 6-dye x 4096-scan electropherograms already
-resident in HBM (BASELINE.json configs[1]).  For N > 1 the driver launches one rank per GPU
-(torch.distributed.run); inference shards by profile, so every rank runs its own batch (weak
-scaling, no data-path collective) and ``value`` is the whole-job profiles/s.
+A step = one eval-mode pass of the shipped U-Net (depth 4, kernel (3,5), 32 filters, config/models/unet.yaml) over one
+batch of 256 synthetic 6-dye x 4096-scan electropherograms already resident in HBM (BASELINE.json configs[1]); ``value``
+is that leg in bf16.  With ``--gpus N`` and no WORLD_SIZE in the environment this script starts the N ranks itself
+(``python -m torch.distributed.run`` as a child, before anything touches the GPU); under a launcher it checks that the
+world size equals ``--gpus`` and refuses to run otherwise.  Inference shards by profile, so every rank runs its own
+batch (weak scaling, no data-path collective) and ``value`` is the whole-job profiles/s.
 
-The JSON line also carries
-  * ``roofline``: the dominant kernel (the bf16 3x5 implicit-GEMM convolution) timed live with HIP
-    events on the launch stream during the timed steps: algorithmic FLOP / launch duration vs the
-    2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md);
-  * ``cpu_baseline``: the CPU oracle (a torch fp32 port of the reference path) timed on this box's
-    host cores on a bounded sample (rank 0, N=1 only);
-  * ``train_step``: fwd + Dice + bwd + Adam profiles/s once the training path is available.
+The one JSON line also carries
+  * ``roofline``: the dominant kernel of the headline leg, timed live with HIP events on the launch stream:
+    algorithmic FLOP / launch duration vs the dense MFMA peak of the dtype (MI355X_MICROARCH.md);
+  * ``legs``: the other halves of configs[1] -- the reference's own precision (fp32) on the same batch, and both
+    precisions on the reference's HIDImage shape (5 dyes) -- each with its own roofline;
+  * ``train_step``: fwd + Dice + bwd + Adam profiles/s (bf16, and fp32 under ``train_step_f32``); data parallel over
+    RCCL when N > 1 (configs[3]: 256 profiles per GPU, and the global batch of 2048 split over the ranks);
+  * ``parity``: mask pixels / called alleles that differ between the bf16 and the fp32 kernels on 64 profiles;
+  * ``cpu_baseline``: the CPU oracle (a torch fp32 port of the reference path) timed on this box's host cores on a
+    bounded sample, inference and one training step (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,32 +35,86 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FWD_FLOP_H5 = 58_531_512_320          # SURVEY 8d, per profile, H=5
+TRAIN_FLOP_H5 = 175_574_876_160       # fwd + dgrad + wgrad per profile, H=5
 BF16_PEAK_TFLOPS = 2500.0             # dense bf16 MFMA peak, MI355X_MICROARCH.md
 F32_PEAK_TFLOPS = 157.3
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="profiles per GPU per step")
     ap.add_argument("--rows", type=int, default=6, help="dye rows (6 = BASELINE.json wording, 5 = reference HIDImage)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="precision of the headline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-legs", action="store_true", help="headline leg only (no fp32 / 5-dye legs, no parity counts)")
+    ap.add_argument("--global-batch", type=int, default=2048, help="configs[3]: global batch of the strong-scaling train leg (N > 1)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous rehearsal on the CPU (gloo, stub step, no GPU): what the tests use")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(rows: int, seconds_budget: float = 20.0):
-    """The oracle (oracle/unet_oracle.py, a port of the reference path) on the host cores."""
+def peak_of(dtype: str) -> float:
+    return BF16_PEAK_TFLOPS if dtype == "bf16" else F32_PEAK_TFLOPS
+
+
+def spawn_ranks(args) -> int:
+    """``--gpus N`` without a launcher: start one rank per GPU as a child job.  Nothing in this process has touched the
+    GPU (importing torch does not), and the child is a child -- never an exec of a process that holds the device."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the only place the oracle is used)
+# ---------------------------------------------------------------------------------------------------------------------
+def host_cpu():
+    """(physical cores this process may use, CPU model) from lscpu / the affinity mask."""
+    model, cores_per_socket, sockets, threads_per_core = "unknown", None, None, 1
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                model = v
+            elif k == "Core(s) per socket":
+                cores_per_socket = int(v)
+            elif k == "Socket(s)":
+                sockets = int(v)
+            elif k == "Thread(s) per core":
+                threads_per_core = int(v)
+    except Exception:
+        pass
+    physical = cores_per_socket * sockets if cores_per_socket and sockets else (os.cpu_count() or 1) // max(1, threads_per_core)
+    return physical, model
+
+
+def cpu_baseline(rows: int, seconds_budget: float = 24.0):
+    """The oracle (oracle/unet_oracle.py, a port of the reference path) on the host cores: eval forward and one
+    training step (fwd + Dice + bwd + Adam), N = 16 each."""
     from oracle import unet_oracle as O
     from dnanet_amd.synthetic import make_batch
-    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    physical, model = host_cpu()
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)         # the box's CPU share for one GPU (16)
+    try:
+        share = min(share or physical, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        share = share or physical
+    cores = max(1, min(physical, share))
     torch.set_num_threads(cores)
     sd = O.init_state_dict(4, (3, 5), 32, seed=0, randomize_bn_stats=True)
-    n = 8
-    x = torch.from_numpy(make_batch(n, rows, 4096, seed=1234)[0])
+    n = 16
+    x_np, t_np = make_batch(n, rows, 4096, seed=1234)
+    x, t = torch.from_numpy(x_np), torch.from_numpy(t_np)
     with torch.no_grad():
         O.unet_forward(sd, x[:2], train=False)                       # warm-up
         t0 = time.perf_counter()
@@ -65,36 +125,122 @@ def cpu_baseline(rows: int, seconds_budget: float = 20.0):
             if time.perf_counter() - t0 > seconds_budget / 2 or done >= 64:
                 break
         dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 3), "unit": "profiles/s", "cores": cores, "kind": "port",
-            "sample": f"{done} synthetic {rows}x4096 profiles, eval forward in batches of {n}, torch fp32 oracle"}
+    out = {"value": round(done / dt, 3), "unit": "profiles/s", "cores": cores, "kind": "port", "cpu_model": model,
+           "physical_cores": physical,
+           "sample": f"{done} synthetic {rows}x4096 profiles, eval forward in batches of {n}, torch fp32 oracle"}
+    state = O.AdamState(O.trainable_keys(sd), sd)
+    O.train_step(sd, x[:2], t[:2], state, 1e-4, 5e-4)                # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        O.train_step(sd, x, t, state, 1e-4, 5e-4)
+        steps += 1
+        if time.perf_counter() - t0 > seconds_budget / 2 or steps >= 3:
+            break
+    dt = time.perf_counter() - t0
+    out["train_step"] = {"value": round(steps * n / dt, 3), "unit": "profiles/s", "ms_per_step": round(dt / steps * 1e3, 1),
+                         "sample": f"{steps} steps of fwd + Dice + bwd + Adam on {n} synthetic {rows}x4096 profiles"}
+    return out
 
 
-TRAIN_FLOP_H5 = 175_574_876_160        # fwd + dgrad + wgrad per profile, H=5
-
-
-def hbm_traffic_per_launch(tag):
-    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the figure
-    comes from the committed rocprofv3 passes of this same command (profiles/README.md; 2 x FETCH_SIZE + WRITE_SIZE,
-    the gfx950 correction of MI355X_MICROARCH.md) and is reported only when it was measured for the kernel that
-    dominates this run; otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU legs
+# ---------------------------------------------------------------------------------------------------------------------
+def hbm_traffic(tag, avg_launch_us):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the figure is
+    the one of the committed rocprofv3 passes of this same command (profiles/README.md; 2 x FETCH_SIZE + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md).  It is reported only for the kernel it was measured on, and only while
+    that kernel's live duration is within 5 % of the profiled one; ``traffic_source`` says where it comes from."""
     try:
-        with open(path) as f:
+        with open(TRAFFIC_PROFILE) as f:
             rec = json.load(f)
     except (OSError, ValueError):
-        return None
-    return round(rec["traffic_bytes_per_launch"]) if rec.get("kernel") == tag else None
+        return None, None
+    if rec.get("kernel") != tag:
+        return None, None
+    ref_us = rec.get("bench_avg_launch_us") or rec.get("rocprof_avg_launch_us")
+    if not ref_us or abs(avg_launch_us - ref_us) > 0.05 * ref_us:
+        return None, f"{os.path.relpath(TRAFFIC_PROFILE, ROOT)} (not reported: live launch {avg_launch_us:.0f} us vs profiled {ref_us:.0f} us)"
+    return round(rec["traffic_bytes_per_launch"]), os.path.relpath(TRAFFIC_PROFILE, ROOT)
 
 
-def train_leg(args, dev, rank, world, distributed, x, t, barrier):
-    """fwd (batch-stat BN) + Dice + bwd + Adam on the same synthetic batch; data parallel over RCCL when N > 1
-    (global batch = 256 x N, Dice sums and the gradient arena all-reduced; BASELINE.json configs[2]/[3])."""
-    from dnanet_amd.unet import HipAdam, HipUNet
+def executed_share(rows: int) -> float:
+    """Share of the nominal 3x5 MFMAs that are issued: the (kernel row, output row) pairs that only see the zero row
+    above / below the image are left out at compile time -- 2 of 3*H pairs."""
+    return 1.0 - 2.0 / (3.0 * rows)
+
+
+def make_eval_model(dtype, dev):
+    from dnanet_amd.unet import HipUNet
     torch.manual_seed(0)
-    model = HipUNet(4, (3, 5), 32, dev, dtype=args.dtype)
+    model = HipUNet(4, (3, 5), 32, dev, dtype=dtype)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():   # randomised BN statistics so the folding is exercised (SURVEY 8d)
+        for key, _, kind in model.spec:
+            if key.endswith("running_mean"):
+                model.tensor(key).copy_(torch.randn(model.tensor(key).shape, generator=g))
+            elif key.endswith("running_var"):
+                model.tensor(key).copy_(0.5 + 1.5 * torch.rand(model.tensor(key).shape, generator=g))
+    model.eval()
+    return model
+
+
+def infer_leg(dtype, rows, batch, steps, warmup, dev, rank, world, barrier, reduce_max):
+    """``steps`` timed eval passes over one resident batch; returns (profiles/s whole job, ms/step, roofline dict)."""
+    from dnanet_amd.synthetic import make_batch
+    model = make_eval_model(dtype, dev)
+    x = torch.from_numpy(make_batch(batch, rows, 4096, seed=1234 + rank)[0]).to(dev)
+    for _ in range(warmup):
+        model.infer(x, want_logits=False)
+    model.profile = None if os.environ.get("DN_BENCH_NO_EVENTS") else []     # (tuning aid: cost of the per-launch events)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.infer(x, want_logits=False)
+    barrier()
+    elapsed = reduce_max(time.perf_counter() - t0)
+    prof, model.profile = model.profile or [], None
+    value = batch * world * steps / elapsed
+    flop_per_profile = FWD_FLOP_H5 * rows / 5
+    by_tag = {}
+    for tag, flops, e0, e1 in prof:
+        d = by_tag.setdefault(tag, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    roofline = None
+    if by_tag:
+        tag, (fl, sec, cnt) = max(by_tag.items(), key=lambda kv: kv[1][1])
+        peak = peak_of(dtype)
+        achieved = fl / sec / 1e12
+        traffic, source = hbm_traffic(tag, sec / cnt * 1e6) if (dtype, rows, batch) == ("bf16", 6, 256) else (None, None)
+        conv_fl = sum(v[0] for v in by_tag.values())
+        conv_sec = sum(v[1] for v in by_tag.values())
+        roofline = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "frac_executed_mfma": round(achieved / peak * executed_share(rows), 4),
+                    "traffic": traffic, "traffic_source": source, "launches": cnt,
+                    "avg_launch_us": round(sec / cnt * 1e6, 2), "share_of_step_time": round(sec / elapsed, 3),
+                    "all_conv_layers_frac": round(conv_fl / conv_sec / 1e12 / peak, 4),
+                    "whole_net_frac": round(value / world * flop_per_profile / 1e12 / peak, 4)}
+    del model, x
+    torch.cuda.empty_cache()
+    return value, elapsed / steps * 1e3, roofline
+
+
+def train_leg(dtype, rows, batch, steps, dev, rank, world, distributed, barrier, reduce_max, label=""):
+    """fwd (batch-stat BN) + Dice + bwd + Adam on one synthetic batch per rank; data parallel over RCCL when N > 1
+    (global batch = batch x N, Dice sums and the gradient arena all-reduced; BASELINE.json configs[2]/[3])."""
+    from dnanet_amd.synthetic import make_batch
+    from dnanet_amd.unet import HipAdam, HipUNet
+    x_np, t_np = make_batch(batch, rows, 4096, seed=1234 + rank)
+    x, t = torch.from_numpy(x_np).to(dev), torch.from_numpy(t_np).to(dev)
+    torch.manual_seed(0)
+    model = HipUNet(4, (3, 5), 32, dev, dtype=dtype)
     model.train()
     opt = HipAdam(model, lr=1e-4, weight_decay=5e-4)
+    comm = None
     if distributed:
+        import torch.distributed as dist
         from dnanet_amd.distributed import DataParallelTrainer
         trainer = DataParallelTrainer(model, opt)
         step = lambda: trainer.step(x, t)
@@ -106,7 +252,6 @@ def train_leg(args, dev, rank, world, distributed, x, t, barrier):
             opt.step()
             opt.zero_grad()
             return sums
-    steps = max(3, args.steps // 4)
     for _ in range(2):
         sums = step()
     barrier()
@@ -115,25 +260,94 @@ def train_leg(args, dev, rank, world, distributed, x, t, barrier):
         sums = step()
     loss = float(sums[4])              # the per-step host sync of the reference loop (trainable_unet.py:347), once here
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = reduce_max(time.perf_counter() - t0)
     if distributed:
-        import torch.distributed as dist
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
-    pps = args.batch * world * steps / elapsed
-    peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
-    return {"value": round(pps, 1), "unit": "profiles/s", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 3),
-            "global_batch": args.batch * world, "loss": round(loss, 5),
-            "parallelism": f"dp{world}" + (" (RCCL sum-all-reduce of Dice sums + bucketed gradient arena)" if world > 1 else ""),
-            "whole_step_mfma_frac": round(pps / world * TRAIN_FLOP_H5 * args.rows / 5 / 1e12 / peak, 4)}
+        buckets = trainer.reducer.last_buckets
+        comm = {"backend": dist.get_backend(), "world_size_seen_by_rank0": dist.get_world_size(),
+                "gradient_buckets_per_step": len(buckets), "bytes_all_reduced_per_step": int(sum(b - a for a, b in buckets) * 4),
+                "dice_sums_all_reduced": 4, "batchnorm": "sync" if getattr(trainer, "sync_bn", False) else "per replica"}
+    pps = batch * world * steps / elapsed
+    out = {"value": round(pps, 1), "unit": "profiles/s", "dtype": "bf16" if dtype == "bf16" else "f32", "steps": steps,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "per_gpu_batch": batch, "global_batch": batch * world,
+           "rows": rows, "loss": round(loss, 5),
+           "parallelism": f"dp{world}" + (" (RCCL sum-all-reduce of Dice sums + bucketed gradient arena)" if world > 1 else ""),
+           "whole_step_mfma_frac": round(pps / world * TRAIN_FLOP_H5 * rows / 5 / 1e12 / peak_of(dtype), 4)}
+    if comm:
+        out["comm"] = comm
+    del model, opt, x, t
+    torch.cuda.empty_cache()
+    return out
+
+
+def parity_leg(dev, n=64):
+    """bf16 kernels vs fp32 kernels at the shipped configuration, on a briefly trained net (sparse masks, like a real
+    model) and on the seeded random-init net of the throughput legs: differing mask pixels and called alleles.  The
+    fp32 kernels themselves are pinned to the reference by the GPU tests (tests/test_parity_bf16_gpu.py, ...)."""
+    from dnanet_amd.parity import briefly_trained_state, disagreement
+    from dnanet_amd.synthetic import make_batch
+    from dnanet_amd.unet import HipUNet
+    x = torch.from_numpy(make_batch(n, 5, 4096, seed=4321, unique=n)[0]).to(dev)
+    out = {"what": f"bf16 kernels vs fp32 kernels, shipped config, {n} synthetic 5x4096 profiles; masks p >= 0.5, alleles by "
+                   "the NearestBasePairCaller hand-off"}
+    states = {"briefly_trained": briefly_trained_state(4, (3, 5), 32, dev)}
+    ref = make_eval_model("fp32", dev)
+    states["random_init"] = {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
+    del ref
+    for name, sd in states.items():
+        probs = {}
+        for dtype in ("fp32", "bf16"):
+            m = HipUNet(4, (3, 5), 32, dev, dtype=dtype)
+            m.load_state_dict(sd)
+            m.eval()
+            probs[dtype] = m.infer(x, want_logits=False)[1]
+            del m
+        out[name] = disagreement(probs["bf16"], probs["fp32"], x)
+    torch.cuda.empty_cache()
+    return out
+
+
+def dry_run(args, rank, world):
+    """Rendezvous rehearsal without a GPU: gloo group, a stub step with the same barrier / max-over-ranks timing."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    ranks = [None] * world
+    if world > 1:
+        dist.all_gather_object(ranks, rank)
+    else:
+        ranks = [0]
+    t0 = time.perf_counter()
+    acc = torch.zeros(4)
+    for _ in range(args.steps):
+        acc += 1
+        if world > 1:
+            dist.all_reduce(acc)
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "profiles/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ranks_seen": sorted(ranks),
+                          "world_size_seen_by_rank0": dist.get_world_size() if world > 1 else 1, "dry_run": True,
+                          "ms_per_step": round(float(elapsed) / max(1, args.steps) * 1e3, 3)}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))                     # parent: argument parsing only, no GPU call before this point
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); refusing to mislabel the run",
+                  file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     distributed = world > 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -141,75 +355,59 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from dnanet_amd.synthetic import make_batch
-    from dnanet_amd.unet import HipUNet
-
-    torch.manual_seed(0)
-    model = HipUNet(4, (3, 5), 32, dev, dtype=args.dtype)
-    g = torch.Generator().manual_seed(1)
-    with torch.no_grad():   # randomised BN statistics so the folding is exercised
-        for key, _, kind in model.spec:
-            if key.endswith("running_mean"):
-                model.tensor(key).copy_(torch.randn(model.tensor(key).shape, generator=g))
-            elif key.endswith("running_var"):
-                model.tensor(key).copy_(0.5 + 1.5 * torch.rand(model.tensor(key).shape, generator=g))
-    model.eval()
-    x_np, t_np = make_batch(args.batch, args.rows, 4096, seed=1234 + rank)
-    x = torch.from_numpy(x_np).to(dev)
-
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        model.infer(x, want_logits=False)
-    model.profile = None if os.environ.get("DN_BENCH_NO_EVENTS") else []     # (tuning aid: cost of the per-launch events)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.infer(x, want_logits=False)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof, model.profile = model.profile or [], None
-    if distributed:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def reduce_max(seconds):
+        if not distributed:
+            return seconds
+        tmax = torch.tensor([seconds], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
+        return float(tmax)
 
-    value = args.batch * world * args.steps / elapsed
-    flop_per_profile = FWD_FLOP_H5 * args.rows / 5
-
-    # roofline of the dominant kernel from the per-launch events of the timed region
-    by_tag = {}
-    for tag, flops, e0, e1 in prof:
-        d = by_tag.setdefault(tag, [0.0, 0.0, 0])
-        d[0] += flops
-        d[1] += e0.elapsed_time(e1) * 1e-3
-        d[2] += 1
-    roofline = None
-    if by_tag:
-        tag, (fl, sec, cnt) = max(by_tag.items(), key=lambda kv: kv[1][1])
-        peak = BF16_PEAK_TFLOPS if args.dtype == "bf16" else F32_PEAK_TFLOPS
-        achieved = fl / sec / 1e12
-        roofline = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": hbm_traffic_per_launch(tag), "launches": cnt,
-                    "avg_launch_us": round(sec / cnt * 1e6, 2),
-                    "share_of_step_time": round(sec / elapsed, 3),
-                    "whole_net_frac": round(value / world * flop_per_profile / 1e12 / peak, 4)}
-
+    common = (dev, rank, world, barrier, reduce_max)
+    value, ms, roofline = infer_leg(args.dtype, args.rows, args.batch, args.steps, args.warmup, *common)
+    dt = lambda d: "bf16" if d == "bf16" else "f32"
     out = {
         "metric": "profiles/sec U-Net inference (pretrained-shape U-Net, batch 256 per GPU)",
         "value": round(value, 1), "unit": "profiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dt(args.dtype), "data": "synthetic",
         "config": {"workload": f"U-Net depth4 k(3,5) f32 eval forward, batch {args.batch}/GPU, {args.rows} dyes x 4096 scans "
-                               "(BASELINE.json configs[1])", "global_batch": args.batch * world,
-                   "parallelism": f"replicas x{world} (inference shards by profile, no collective)"},
+                               f"(BASELINE.json configs[1], {args.dtype} half)", "global_batch": args.batch * world,
+                   "parallelism": f"replicas x{world} (inference shards by profile, no collective)",
+                   "world_size_seen_by_rank0": world},
         "roofline": roofline,
     }
+    if not args.no_legs and not distributed:
+        # the other halves of configs[1]: the reference's precision on the same batch, and the reference's HIDImage shape
+        legs = {}
+        other = "fp32" if args.dtype == "bf16" else "bf16"
+        for name, (d, rows) in {f"infer_{dt(other)}_h{args.rows}": (other, args.rows), "infer_bf16_h5": ("bf16", 5),
+                                "infer_f32_h5": ("fp32", 5)}.items():
+            steps = max(3, args.steps // 4) if d == "fp32" else max(5, args.steps // 2)
+            v, m, r = infer_leg(d, rows, args.batch, steps, min(2, args.warmup), *common)
+            legs[name] = {"value": round(v, 1), "unit": "profiles/s", "dtype": dt(d), "rows": rows, "batch": args.batch,
+                          "steps": steps, "ms_per_step": round(m, 3), "roofline": r}
+        out["legs"] = legs
+        out["parity"] = parity_leg(dev)
     if not args.no_train:
-        out["train_step"] = train_leg(args, dev, rank, world, distributed, x, torch.from_numpy(t_np).to(dev), barrier)
+        tsteps = max(3, args.steps // 4)
+        out["train_step"] = train_leg(args.dtype, args.rows, args.batch, tsteps, dev, rank, world, distributed, barrier, reduce_max)
+        if distributed and args.global_batch % world == 0:
+            # configs[3]: the same global batch on 2 / 4 / 8 GPUs (strong scaling of the training step)
+            per = args.global_batch // world
+            try:
+                out["train_step_global"] = train_leg(args.dtype, args.rows, per, 3, dev, rank, world, True, barrier, reduce_max)
+                out["train_step_global"]["scaling"] = "strong"
+            except Exception as exc:      # e.g. out of memory at 1024 profiles per GPU: report, keep the line
+                out["train_step_global"] = {"error": f"{type(exc).__name__}: {exc}"[:300], "per_gpu_batch": per}
+        if not distributed and not args.no_legs:
+            other = "fp32" if args.dtype == "bf16" else "bf16"
+            out[f"train_step_{dt(other)}"] = train_leg(other, args.rows, args.batch, 3, dev, rank, world, False, barrier, reduce_max)
+            out["train_step_bf16_h5"] = train_leg("bf16", 5, args.batch, tsteps, dev, rank, world, False, barrier, reduce_max)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.rows)
     if rank == 0:

@@ -61,14 +61,20 @@ def run(data_config, model_config, training_config, evaluation_config, nr_folds,
     if gpus > 1:
         # one process per fold, fold i on GPU (i-1) mod gpus, at most `gpus` at a time; the split is deterministic
         # (seed 42), so every worker derives the same folds
-        import torch
-        n_devices = max(1, torch.cuda.device_count())     # counting devices does not initialise the GPU in this process
+        # fold -> GPU through the parent's own lease: if HIP_VISIBLE_DEVICES already restricts this process (e.g. "4,5"),
+        # the workers get entries of THAT list, never a bare index outside it
+        visible = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d.strip()]
+        if not visible:
+            import torch
+            visible = [str(d) for d in range(max(1, torch.cuda.device_count()))]
         pending = list(range(1, nr_folds + 1))
         while pending:
             batch, pending = pending[:gpus], pending[gpus:]
             procs = []
             for slot, i in enumerate(batch):
-                env = dict(os.environ, HIP_VISIBLE_DEVICES=str(slot % n_devices), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                env = dict(os.environ, HIP_VISIBLE_DEVICES=visible[slot % len(visible)], HSA_ENABLE_IPC_MODE_LEGACY="0")
+                for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):     # a fold worker is a single-device job of its own
+                    env.pop(key, None)
                 cmd = [sys.executable, os.path.abspath(__file__), "-d", data_config, "-m", model_config, "-t", training_config,
                        "-e", evaluation_config, "-k", str(nr_folds), "-o", output_dir, "--only-fold", str(i)]
                 if validation_config:

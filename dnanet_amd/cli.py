@@ -22,6 +22,10 @@ def start_run(kind: str, output_dir: Optional[str], log_name: str) -> str:
     os.makedirs(output_dir, exist_ok=True)
     if not LOGGER.handlers:
         logging.basicConfig(level=logging.INFO, format="%(asctime)s %(name)s %(levelname)s %(message)s")
+    if int(os.environ.get("RANK", "0")) != 0:
+        # one rank per GPU: rank 0 owns the log file, the others only report problems
+        LOGGER.setLevel(logging.WARNING)
+        return output_dir
     LOGGER.setLevel(logging.INFO)
     handler = logging.FileHandler(os.path.join(output_dir, log_name))
     handler.setFormatter(logging.Formatter("%(asctime)s %(levelname)s %(message)s"))

@@ -7,6 +7,9 @@
 
 static thread_local char g_err[512] = "";
 
+// the DN_TUNE_* switches are read here, once, when the library is loaded
+__attribute__((constructor)) static void dn_read_tuning_switches() { (void)dn_tune(); }
+
 int dn_set_error(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -21,23 +24,20 @@ struct ConvVariant { bool wave8; int ht, cot; };
 static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype) {
   ConvVariant v{false, 5, (p.cout_pad % 64 == 0) ? 64 : 32};
   if (kh == 3 && kw == 5 && p.H % 3 == 0 && p.H % 5 != 0) v.ht = 3;   // e.g. 6 dye rows = two 3-row tiles
-  static const char* force_cot = getenv("DN_TUNE_COT");      // tuning aid: DN_TUNE_COT=32 forces the narrow tile
-  if (force_cot && atoi(force_cot) == 32) v.cot = 32;
+  const DnTune& tune = dn_tune();
+  if (tune.cot == 32) v.cot = 32;
   // narrow (32-channel) tiles have room for 6 accumulator rows: one 6-row tile instead of two 3-row ones halves the
   // per-block fixed cost that dominates the 2-4 chunk layers
   if (kh == 3 && kw == 5 && v.cot == 32 && v.ht == 3 && p.H % 6 == 0) v.ht = 6;
   // a 1x1 GEMM (transposed convolution) is bound by how often the activation tile is re-streamed from L2: 128 output
   // channels x 2 rows halves that against 64 x 5 (rows are 128-pixel slices of the flattened plane, so H is even)
-  static const char* no128 = getenv("DN_TUNE_NO_COT128");
-  if (!no128 && kh == 1 && kw == 1 && p.cout_pad % 128 == 0 && p.H % 2 == 0) { v.ht = 2; v.cot = 128; return v; }
-  static const char* no8 = getenv("DN_TUNE_NO_CONV8");        // tuning aid: keep the 4-wave kernel everywhere
+  if (!tune.no_cot128 && kh == 1 && kw == 1 && p.cout_pad % 128 == 0 && p.H % 2 == 0) { v.ht = 2; v.cot = 128; return v; }
   // measured (N=256, W=4096 net): the 8-wave kernels win for 5-row tiles and for fp32; bf16 3-row tiles (6 dyes) are
   // faster on the 4-wave kernel at every level
-  static const char* ht3_8 = getenv("DN_TUNE_CONV8_HT3");      // tuning aid: 8-wave kernel for bf16 3-row tiles too
-  v.wave8 = !no8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) && (dtype == DN_F32 || (dtype == DN_BF16 && (v.ht == 5 || ht3_8)));
+  v.wave8 = !tune.no_conv8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) &&
+            (dtype == DN_F32 || (dtype == DN_BF16 && (v.ht == 5 || tune.conv8_ht3)));
   if (p.head_w) v.wave8 = false;     // the fused head lives in the 4-wave kernel's epilogue
-  static const char* stats4 = getenv("DN_TUNE_STATS_4WAVE");   // tuning aid: fused-statistics convolutions on the 4-wave kernel
-  if (p.stats && stats4) v.wave8 = false;
+  if (p.stats && tune.stats_4wave) v.wave8 = false;
   // Small batches (train.py's 16 profiles): the wide tiles leave CUs idle -- every 8-wave launch of the shipped net
   // is exactly 128 workgroups at N = 16.  Step down to the tile that still gives two workgroups per CU.
   if (p.N > 0) {
@@ -78,7 +78,7 @@ static void flatten_rows(ConvParams& p) {
 extern "C" {
 
 const char* dn_last_error(void) { return g_err; }
-int dn_abi_version(void) { return 1; }
+int dn_abi_version(void) { return 2; }
 
 int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len) {
   DN_CHECK_ARG(buf && buf_len > 0, "dn_conv2d_variant: no buffer");
@@ -100,6 +100,7 @@ static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_
 static bool head_fits(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype) {
   if (!((kh == 3 && kw == 5) || (kh == 1 && kw == 3)) || cin <= 1 || cout <= 0 || N <= 0 || H <= 0 || W <= 0) return false;
   if (dtype != DN_BF16 && dtype != DN_F32) return false;
+  if (dn_tune().no_head_fuse) return false;
   ConvParams p{};
   static const float one = 1.f;
   p.N = N; p.H = H; p.W = W; p.nchunk = dn_planes(cin, dtype); p.cout_pad = dn_channel_pad(cout); p.x_wmul = 1; p.y_wmul = 1;

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #define DN_OK 0
 #define DN_ERR_ARG 1
@@ -37,6 +38,41 @@ struct TensorRef {
 };
 
 int dn_set_error(int code, const char* fmt, ...);
+
+// Tuning aids (DN_TUNE_* environment variables, A/B switches for the measurements in DESIGN.md).  They are read ONCE,
+// into this struct, when the library is loaded (api.hip calls dn_tune() from a constructor); the dispatch code only
+// looks at the struct.  All zero = the shipped behaviour.
+struct DnTune {
+  int cot;              // DN_TUNE_COT=32: force the narrow output-channel tile
+  bool no_cot128;       // DN_TUNE_NO_COT128: no 128-channel tile for the 1x1 GEMMs
+  bool no_conv8;        // DN_TUNE_NO_CONV8: 4-wave kernel everywhere
+  bool conv8_ht3;       // DN_TUNE_CONV8_HT3: 8-wave kernel for bf16 3-row tiles too
+  bool stats_4wave;     // DN_TUNE_STATS_4WAVE: fused-statistics convolutions on the 4-wave kernel
+  bool k11_kp1;         // DN_TUNE_K11_KP1: 1x1 GEMM stages one plane per barrier
+  bool no_head_fuse;    // DN_TUNE_NO_HEAD_FUSE: dn_conv2d_head_supported() says no
+  long wgrad_blocks;    // DN_TUNE_WGRAD_BLOCKS: split-K target grid size (0 = default 512)
+  int wgrad_noskip;     // DN_TUNE_WGRAD_NOSKIP: 1 = multiply the zero halo rows too, 2 = interleaved tap map
+  bool no_bn_fuse;      // DN_TUNE_NO_BN_FUSE: training keeps the separate BatchNorm passes (no fused epilogues)
+};
+inline const DnTune& dn_tune() {
+  static const DnTune t = [] {
+    DnTune v{};
+    auto flag = [](const char* name) { const char* e = getenv(name); return e && *e && *e != '0'; };
+    const char* e;
+    if ((e = getenv("DN_TUNE_COT"))) v.cot = atoi(e);
+    v.no_cot128 = flag("DN_TUNE_NO_COT128");
+    v.no_conv8 = flag("DN_TUNE_NO_CONV8");
+    v.conv8_ht3 = flag("DN_TUNE_CONV8_HT3");
+    v.stats_4wave = flag("DN_TUNE_STATS_4WAVE");
+    v.k11_kp1 = flag("DN_TUNE_K11_KP1");
+    v.no_head_fuse = flag("DN_TUNE_NO_HEAD_FUSE");
+    if ((e = getenv("DN_TUNE_WGRAD_BLOCKS"))) v.wgrad_blocks = atol(e);
+    if ((e = getenv("DN_TUNE_WGRAD_NOSKIP"))) v.wgrad_noskip = atoi(e) == 2 ? 2 : 1;
+    v.no_bn_fuse = flag("DN_TUNE_NO_BN_FUSE");
+    return v;
+  }();
+  return t;
+}
 #define DN_CHECK_ARG(cond, ...) do { if (!(cond)) return dn_set_error(DN_ERR_ARG, __VA_ARGS__); } while (0)
 #define DN_CHECK_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
   return dn_set_error(DN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)

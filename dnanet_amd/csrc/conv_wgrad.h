@@ -373,8 +373,7 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   p.ci_pad = (p.ci_pad + CI_T - 1) / CI_T * CI_T;
   const long tiles = (long)(p.co_pad / TR::CO_T) * (p.ci_pad / CI_T);
   const long per_slab = (long)TAPS * p.co_pad * p.ci_pad * 4 * (KSPLIT ? 4 : 1);
-  static const char* tune_blocks = getenv("DN_TUNE_WGRAD_BLOCKS");   // tuning aid: split-K target grid size
-  const long target = tune_blocks ? atol(tune_blocks) : 512;   // two resident workgroups per CU
+  const long target = dn_tune().wgrad_blocks > 0 ? dn_tune().wgrad_blocks : 512;   // two resident workgroups per CU
   long nsplit = std::max<long>(1, (target + tiles - 1) / tiles);
   // >= 2048 pixels per block: every slab costs a round trip through HBM
   nsplit = std::min<long>(nsplit, std::max<long>(1, (long)p.nstrips * HT * SW / 2048));
@@ -382,8 +381,7 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   if (nsplit >= p.nth) nsplit -= nsplit % p.nth;   // blocks of one height in the image (halo-row skipping)
   if (nsplit < 1) return dn_set_error(DN_ERR_ARG, "conv_wgrad: workspace of %ld bytes is smaller than one partial slab (%ld)",
                                       slab_bytes, per_slab);
-  static const char* noskip = getenv("DN_TUNE_WGRAD_NOSKIP");   // tuning aid
-  p.skip_halo = noskip ? atoi(noskip) == 2 ? 2 : 0 : 1;
+  p.skip_halo = dn_tune().wgrad_noskip == 2 ? 2 : dn_tune().wgrad_noskip == 1 ? 0 : 1;
   p.nsplit = (int)nsplit;
   *nslab_out = (int)nsplit * (KSPLIT ? 4 : 1);
   hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, HT>), dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, p);

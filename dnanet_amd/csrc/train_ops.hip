@@ -719,11 +719,14 @@ int dn_channel_sum(dn_tensor x, float* out, float* partial, int N, int H, int W,
   return DN_OK;
 }
 
-int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial, int N, int H, int W, int kh, int kw, int dtype,
-                        void* stream) {
+int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial, long partial_floats, int N, int H, int W, int kh,
+                        int kw, int dtype, void* stream) {
   DN_CHECK_ARG(x && dy.base && dw && partial, "dn_conv_first_wgrad: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && dy.channels > 0, "dn_conv_first_wgrad: bad shape");
   const int C = dy.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype), taps = kh * kw;
   const int nblk = dn_conv_first_wgrad_blocks(N, H, W);
+  DN_CHECK_ARG((long)nblk * taps * cpad <= partial_floats, "dn_conv_first_wgrad: partial buffer of %ld floats, need %ld",
+               partial_floats, (long)nblk * taps * cpad);
   hipStream_t s = (hipStream_t)stream;
   DN_CHECK_ARG((long)N * H * W < (1L << 31), "dn_conv_first_wgrad: more than 2^31 pixels");
 #define LAUNCH(TT, KH, KW) hipLaunchKernelGGL((conv_first_wgrad_kernel<TT, KH, KW>), dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, x, \

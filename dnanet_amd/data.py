@@ -96,6 +96,29 @@ class ArrayImage:
     _panel: Optional[Panel] = None
 
 
+def shared_seed(seed):
+    """The seed every rank of a torch.distributed job must use for a split / shuffle.  ``random.seed(None)`` seeds from
+    OS entropy per process, which would give every rank its own training / validation split (and, in ``fit``, ranks that
+    disagree about early stopping and hang in a collective): inside an initialised process group of more than one rank
+    a missing seed is drawn on rank 0 and broadcast.  Outside a group, or with an explicit seed, it is returned as is
+    (the reference's behaviour, ``DNAnet/data/data_models/base.py:69-111``)."""
+    if seed is not None:
+        return seed
+    try:
+        import torch.distributed as dist
+    except Exception:  # pragma: no cover
+        return seed
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise RuntimeError("an unseeded split / shuffle inside a multi-rank job needs the process group to be "
+                               "initialised first (every rank would draw its own split); pass a seed or call "
+                               "torch.distributed.init_process_group before splitting")
+        return seed
+    box = [random.SystemRandom().randrange(1 << 62) if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def chunks(iterable: Iterable, chunk_size: int, skip_remainder: bool = False) -> Iterator[List]:
     """Consecutive batches of ``chunk_size`` (the last one may be shorter unless ``skip_remainder``);
     same contract as ``DNAnet/utils.py:136-171``."""
@@ -127,13 +150,15 @@ class ArrayDataset(Sequence):
 
     def __iter__(self):
         if self.shuffle:
-            return iter(random.sample(self._data, len(self._data)))
+            seed = shared_seed(None)
+            rng = random.Random(seed) if seed is not None else random
+            return iter(rng.sample(self._data, len(self._data)))
         return iter(self._data)
 
     def split(self, fraction: float, seed: Optional[float] = None) -> Tuple["ArrayDataset", "ArrayDataset"]:
         if not 0 < fraction < 1:
             raise ValueError(f"Fraction should be between 0 and 1, got {fraction}.")
-        random.seed(seed)
+        random.seed(shared_seed(seed))
         order = random.sample(self._data, len(self._data))
         cut = int(len(order) * fraction)
         return ArrayDataset(order[:cut], self.shuffle), ArrayDataset(order[cut:], self.shuffle)
@@ -141,7 +166,7 @@ class ArrayDataset(Sequence):
     def split_k_fold(self, n_folds: int, seed: Optional[float] = None) -> List[Tuple["ArrayDataset", "ArrayDataset"]]:
         if n_folds < 2 or n_folds > len(self._data):
             raise ValueError(f"Cannot make {n_folds} folds out of {len(self._data)} images.")
-        random.seed(seed)
+        random.seed(shared_seed(seed))
         order = random.sample(self._data, len(self._data))
         base, extra = divmod(len(order), n_folds)
         folds = [order[i * base:(i + 1) * base] for i in range(n_folds)]

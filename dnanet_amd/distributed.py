@@ -89,6 +89,7 @@ class ArenaAllReducer:
         self.stream = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
         self._by_name = {n: (a, b) for n, a, b in self.segments}
         self.launched: List[Tuple[int, int]] = []
+        self.last_buckets: List[Tuple[int, int]] = []     # the (start, stop) ranges the latest step reduced
 
     def _launch(self, lo: int, hi: int):
         view = self.flat[lo:hi]
@@ -120,6 +121,7 @@ class ArenaAllReducer:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._works, done = [], self.launched
         self.launched = []
+        self.last_buckets = done
         return done
 
 

@@ -64,7 +64,7 @@ _SIGS = {
     "dn_conv2d_wgrad": (c_int, [DnTensor, DnTensor, _P, _P, c_long] + [c_int] * 8 + [_P]),
     "dn_conv_transpose_1x2_wgrad": (c_int, [DnTensor, DnTensor, _P, _P, c_long, c_int, c_int, c_int, c_int, _P]),
     "dn_conv_first_wgrad_blocks": (c_int, [c_int, c_int, c_int]),
-    "dn_conv_first_wgrad": (c_int, [_P, DnTensor, _P, _P] + [c_int] * 6 + [_P]),
+    "dn_conv_first_wgrad": (c_int, [_P, DnTensor, _P, _P, c_long] + [c_int] * 6 + [_P]),
     "dn_dice_forward": (c_int, [_P, _P, c_long, _P, _P, _P]),
     "dn_dice_backward": (c_int, [_P, _P, c_long, _P, _P, _P]),
     "dn_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_long, c_float, c_int, _P]),
@@ -132,6 +132,11 @@ def channel_pad(c: int) -> int:
 
 def partial_floats(c: int) -> int:
     return 512 * channel_pad(c) * 2 + 4096
+
+
+def first_wgrad_partial_floats(cout: int, kh: int, kw: int, blocks: int = 512) -> int:
+    """Capacity ``dn_conv_first_wgrad`` needs in its ``partial`` workspace (``blocks`` = its largest grid)."""
+    return blocks * kh * kw * channel_pad(cout)
 
 
 def planes(c: int, dtype: int) -> int:

@@ -327,6 +327,13 @@ class DNANet_UNet(TrainableModel):
             if validation_set:
                 validation_metric = self.compute_metric(metrics[0], validation_set, batch_size) if metrics else float("nan")
                 validation_loss = self.compute_validation_loss(validation_set, batch_size, descr, steps_per_epoch_val, metrics)
+                if self._group_size() > 1:
+                    # save_best (a barrier inside save()) and early stopping branch on this value: every rank takes
+                    # rank 0's, so no rank can leave the loop or enter a collective alone
+                    import torch.distributed as dist
+                    box = [validation_loss, validation_metric]
+                    dist.broadcast_object_list(box, src=0)
+                    validation_loss, validation_metric = box
                 LOGGER.info(f"{descr} - Validation metric ({metrics[0] if metrics else None}): {validation_metric:.6f} | "
                             f"Validation loss: {validation_loss:.6f}")
                 _log_metric("validation_loss", validation_loss, epoch)

@@ -213,7 +213,7 @@ class HipUNet(ParameterTree):
             self._conv(units[pre + ".0"], cache[pre + ".0"], both, tmp.ref(c[l]), n, h, ws[l])
             last = units[pre + ".3"]
             kh, kw = self.kernel_size
-            if l == 0 and not os.environ.get("DN_TUNE_NO_HEAD_FUSE") and hip.lib.dn_conv2d_head_supported(last.cin, last.cout, n, h, w, kh, kw, dt):
+            if l == 0 and hip.lib.dn_conv2d_head_supported(last.cin, last.cout, n, h, w, kh, kw, dt):
                 # the 1x1 output convolution + sigmoid ride in the last convolution's epilogue: its activation is never stored
                 entry = cache[pre + ".3"]
                 if self.profile is not None:
@@ -266,8 +266,12 @@ class HipUNet(ParameterTree):
     def _workspace(self):
         if self._ws is None:
             cmax = self.num_filters * 2 ** self.depth
+            kh, kw = self.kernel_size
+            # reduction partials: the per-channel reductions need dn_partial_floats(C); the first convolution's weight
+            # gradient needs (up to 512 blocks) x taps x channel_pad(filters), which is the larger one for small nets
+            partial = max(hip.partial_floats(cmax), hip.first_wgrad_partial_floats(self.num_filters, kh, kw)) + 65536
             self._ws = {
-                "partial": torch.empty(hip.partial_floats(cmax) + 65536, dtype=torch.float32, device=self.device),
+                "partial": torch.empty(partial, dtype=torch.float32, device=self.device),
                 "coef": torch.empty(3 * hip.channel_pad(cmax), dtype=torch.float32, device=self.device),
                 "wgrad": torch.empty(self.wgrad_workspace_bytes, dtype=torch.uint8, device=self.device),
                 "dice_sums": torch.zeros(8, dtype=torch.float32, device=self.device),
@@ -456,7 +460,8 @@ class HipUNet(ParameterTree):
         # the conv bias feeds a BatchNorm: its gradient is identically zero, the arena entry stays 0
         if u.cin == 1:
             hip.check(hip.lib.dn_conv_first_wgrad(hip.ptr(self._saved["x"]), g, hip.ptr(self.grad(u.conv + ".weight")),
-                                                  hip.ptr(ws["partial"]), n, h, w, kh, kw, self.dtype, hip.stream_ptr()))
+                                                  hip.ptr(ws["partial"]), ws["partial"].numel(), n, h, w, kh, kw, self.dtype,
+                                                  hip.stream_ptr()))
             return None
         hip.check(hip.lib.dn_conv2d_wgrad(g, sv["src"], hip.ptr(self.grad(u.conv + ".weight")), hip.ptr(ws["wgrad"]),
                                           ws["wgrad"].numel(), n, h, w, kh, kw, u.cin, u.split, self.dtype, hip.stream_ptr()))

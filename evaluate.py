@@ -15,8 +15,13 @@ def run(data_config, model_config, evaluation_config=None, output_dir=None, chec
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:                                   # one rank per GPU: pick it before the model is built on "cuda"
         import torch
+        import torch.distributed as dist
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            # before the dataset is split: an unseeded split is agreed on through the group (dnanet_amd.data.shared_seed).
+            # gloo: the only exchanges are that seed and the ordered gather of host objects
+            dist.init_process_group("gloo")
     output_dir = start_run("evaluate", output_dir, "log_evaluation.txt")
     LOGGER.info("Loading model...")
     model = load_model(model_config)
@@ -33,8 +38,6 @@ def run(data_config, model_config, evaluation_config=None, output_dir=None, chec
         # launched with torch.distributed.run: every rank predicts its shard, rank 0 scores
         import torch.distributed as dist
         from dnanet_amd.distributed import predict_batch_sharded
-        if not dist.is_initialized():
-            dist.init_process_group("gloo")       # the only exchange is the ordered gather of host objects
         predictions = predict_batch_sharded(model, dataset)
         if dist.get_rank() != 0:
             return {}

@@ -180,10 +180,11 @@ int dn_conv2d_wgrad(dn_tensor dy, dn_tensor a, float* dw, void* workspace, long 
 int dn_conv_transpose_1x2_wgrad(dn_tensor dy, dn_tensor x, float* dw, void* workspace, long workspace_bytes, int N, int H,
                                 int Win, int dtype, void* stream);
 /* Weight gradient of the first convolution (Cin = 1) against the raw fp32 input x[N][1][H][W]: dw[cout][1][kh][kw].
- * partial: dn_conv_first_wgrad_blocks(N,H,W) * kh*kw * dn_channel_pad(cout) floats. */
+ * partial: dn_conv_first_wgrad_blocks(N,H,W) * kh*kw * dn_channel_pad(cout) floats (at most 512 blocks);
+ * partial_floats = capacity of that buffer, checked. */
 int dn_conv_first_wgrad_blocks(int N, int H, int W);
-int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial, int N, int H, int W, int kh, int kw, int dtype,
-                        void* stream);
+int dn_conv_first_wgrad(const float* x, dn_tensor dy, float* dw, float* partial, long partial_floats, int N, int H, int W, int kh,
+                        int kw, int dtype, void* stream);
 /* DiceLoss.forward (loss.py:9-20) + BinaryAccuracy counts (trainable_unet.py:411-415) in one pass over the
  * whole batch: sums[0..4] = { sum p*t, sum p, sum t, #(p>=0.5)==t, loss }.  partial: 4096 floats. */
 int dn_dice_forward(const float* logits, const signed char* targets, long n, float* sums, float* partial, void* stream);

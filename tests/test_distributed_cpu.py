@@ -122,3 +122,46 @@ def test_predict_batch_sharded_gloo_world2(tmp_path):
     out = tmp_path / "ok.txt"
     mp.spawn(_sharded_predict_worker, args=(2, port, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def _split_worker(rank, world, port, out_dir):
+    import os
+    import random
+    import torch.distributed as dist
+    from dnanet_amd.cli import split_validation
+    from dnanet_amd.data import ArrayDataset
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    random.seed(1000 + rank)                       # the ranks' own generators disagree, like processes seeded from entropy
+    data = ArrayDataset(list(range(40)))
+    train, val = split_validation(data, "0.25")    # train.py's `-v 0.25`: an unseeded split
+    part, _ = data.split(0.5)                      # `-s 0.5` without `-rs`
+    shuffled = list(ArrayDataset(list(range(10)), shuffle=True))
+    folds = data.split_k_fold(4)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(repr((list(train), list(val), list(part), shuffled, [list(t) for _, t in folds])))
+    dist.destroy_process_group()
+
+
+def test_unseeded_splits_agree_across_ranks_gloo_world2(tmp_path):
+    """Every rank of a data-parallel job builds its own dataset objects: an unseeded split / shuffle must still be the
+    same on all of them (rank 0 draws the seed), or the ranks train on different sets and fit()'s collectives hang."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_split_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (tmp_path / "rank0.txt").read_text(), (tmp_path / "rank1.txt").read_text()
+    assert a == b
+    train, val, part, shuffled, folds = eval(a)
+    assert len(train) == 30 and len(val) == 10 and sorted(train + val) == list(range(40)) and len(part) == 20
+    assert sorted(shuffled) == list(range(10))
+
+
+def test_unseeded_split_in_multirank_env_without_group_is_refused(monkeypatch):
+    from dnanet_amd.data import ArrayDataset
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError):
+        ArrayDataset(list(range(10))).split(0.5)
+    assert len(ArrayDataset(list(range(10))).split(0.5, seed=3)[0]) == 5      # a seeded split needs no group

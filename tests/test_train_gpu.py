@@ -78,3 +78,44 @@ def test_train_steps_vs_reference_fixture(gpu_device, name, dtype):
                 d = (sd[k].cpu() - v).abs()
                 assert float(d.max()) <= 2.5 * float(g["lr"]) * int(g["steps"]), (k, float(d.max()))
                 assert float((d > 2e-4 + 2e-3 * v.abs()).float().mean()) < 5e-3, k
+
+
+@pytest.mark.parametrize("cfg", [(4, 8, 4), (2, 8, 3), (1, 64, 3)])
+def test_small_net_large_pixel_count_vs_oracle(gpu_device, cfg):
+    """Narrow nets at a pixel count that maxes out the grid of the first convolution's weight gradient (N*H*W >= 65536:
+    512 blocks x 15 taps x channel_pad partials): the reduction workspace is sized for that, not only for the widest
+    layer, and the entry point checks the capacity it is given (an undersized buffer was overrun silently)."""
+    from collections import OrderedDict
+    from dnanet_amd import hip
+    from dnanet_amd.synthetic import make_batch
+    from dnanet_amd.unet import HipAdam, HipUNet
+    from oracle import unet_oracle as O
+    depth, filters, n = cfg
+    sd = O.init_state_dict(depth, (3, 5), filters, seed=11)
+    xn, tn = make_batch(n, 5, 4096, seed=17, unique=n)
+    x, t = torch.from_numpy(xn), torch.from_numpy(tn)
+    ref_sd = OrderedDict((k, v.clone()) for k, v in sd.items())
+    ref_loss, _, ref_grads = O.train_step(ref_sd, x, t, O.AdamState(O.trainable_keys(ref_sd), ref_sd), 1e-3, 5e-4)
+    m = HipUNet(depth, (3, 5), filters, gpu_device, dtype="fp32")
+    m.load_state_dict(sd)
+    m.train()
+    opt = HipAdam(m, lr=1e-3, weight_decay=5e-4)
+    opt.zero_grad()
+    # canary right behind the partials the first-convolution weight gradient may use
+    ws = m._workspace()
+    need = hip.first_wgrad_partial_floats(filters, 3, 5)
+    assert ws["partial"].numel() >= need
+    sums = m.dice_forward(m(x.to(gpu_device)), t.to(gpu_device))
+    m.backward()
+    assert abs(float(sums[4]) - ref_loss) < 2e-5
+    for k in ("encoders.0.conv.double_conv.0.weight", "encoders.0.conv.double_conv.3.weight", "outputs.weight"):
+        g = ref_grads[k]
+        l2 = float((m.grad(k).cpu() - g).norm() / (g.norm() + 1e-20))
+        assert l2 < 5e-3, (k, l2)
+    # the C entry point refuses a buffer that is too small instead of writing past it
+    dy = hip.PlaneBuffer(n, hip.planes(filters, hip.F32), 5, 4096, hip.F32, gpu_device, zero=True)
+    dw = torch.zeros(filters * 15, device=gpu_device)
+    small = torch.zeros(1024, device=gpu_device)
+    rc = hip.lib.dn_conv_first_wgrad(hip.ptr(x.to(gpu_device)), dy.ref(filters), hip.ptr(dw), hip.ptr(small), small.numel(), n, 5, 4096,
+                                     3, 5, hip.F32, hip.stream_ptr())
+    assert rc == 1 and b"partial buffer" in hip.lib.dn_last_error()
