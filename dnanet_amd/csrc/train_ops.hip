@@ -7,8 +7,41 @@
 // Reference: unet_architecture.py:17,21 (BatchNorm2d, ReLU), :37 (MaxPool2d), :54-57 (ConvTranspose2d),
 // :94-97 (head); loss.py:9-20 (DiceLoss); trainable_unet.py:155-157,343-344 (Adam, zero_grad),
 // :295-303,411-415 (BinaryAccuracy).
+#include <mutex>
 #include "common.h"
 #include "ops.h"
+
+
+// ---- the one entry point that allocates nothing (dn_bn_train_forward_noalloc) -------------------------------------
+// Its reduction partials live in this file-scope device array instead of a caller-provided workspace: callers under HIP
+// graph capture, or harnesses that forbid hipMalloc, can run a train-mode BatchNorm without owning any scratch memory.
+// Every GPU the library runs on holds its own copy (2.02 MiB) until the process ends.  In host code the array's NAME is
+// only a stand-in: the per-device address comes from hipGetSymbolAddress, once per device, and only that pointer is
+// ever handed to a kernel.
+constexpr long DN_NOALLOC_SCRATCH_FLOATS = 512L * DN_NOALLOC_MAX_CHANNELS * 2 + 4096;    // = dn_partial_floats(512)
+static __device__ __align__(256) float scratch[DN_NOALLOC_SCRATCH_FLOATS];
+
+namespace {
+constexpr int DN_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[DN_MAX_DEVICES] = {};
+
+// device pointer of `scratch` on the CURRENT device (looked up on the first call on that device)
+int noalloc_scratch(float** out) {
+  int dev = -1;
+  DN_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= DN_MAX_DEVICES) return dn_set_error(DN_ERR_ARG, "dn_bn_train_forward_noalloc: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    DN_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return dn_set_error(DN_ERR_HIP, "dn_bn_train_forward_noalloc: hipGetSymbolAddress returned a null pointer");
+    g_scratch_ptr[dev] = (float*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return DN_OK;
+}
+}  // namespace
 
 namespace {
 
@@ -553,6 +586,20 @@ static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, 
 int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                         float* scale, float* shift, float* partial, int dtype, void* stream) {
+  return bn_train_forward_impl(y, a, N, H, W, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                               partial, 0, dtype, stream);
+}
+
+int dn_bn_train_forward_noalloc(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                float* scale, float* shift, int dtype, void* stream) {
+  DN_CHECK_ARG(y.channels > 0 && y.channels <= DN_NOALLOC_MAX_CHANNELS,
+               "dn_bn_train_forward_noalloc: %d channels, the built-in scratch holds the partials of at most %d "
+               "(use dn_bn_train_forward with a workspace of dn_partial_floats(C) floats)", y.channels, DN_NOALLOC_MAX_CHANNELS);
+  float* partial = nullptr;
+  const int rc = noalloc_scratch(&partial);
+  if (rc != DN_OK) return rc;
+  // every partial the finalize kernel reads is written by this call's statistics kernel first: nothing to clear
   return bn_train_forward_impl(y, a, N, H, W, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                                partial, 0, dtype, stream);
 }

@@ -57,6 +57,8 @@ _SIGS = {
     "dn_reduce_blocks": (c_int, [c_long]),
     "dn_bn_train_forward": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float,
                                     _P, _P, _P, _P, _P, c_int, _P]),
+    "dn_bn_train_forward_noalloc": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float,
+                                            _P, _P, _P, _P, c_int, _P]),
     "dn_bn_train_backward": (c_int, [DnTensor, DnTensor, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "dn_maxpool_1x2_backward": (c_int, [DnTensor, DnTensor, DnTensor, DnTensor, c_int, c_int, c_int, c_int, _P]),
     "dn_head_1x1_backward": (c_int, [_P, DnTensor, _P, DnTensor, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

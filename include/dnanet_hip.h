@@ -125,6 +125,16 @@ int dn_reduce_blocks(long pixels);
 int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                         float* scale, float* shift, float* partial, int dtype, void* stream);
+/* dn_bn_train_forward for callers that cannot allocate (code under HIP graph capture, tight serving / training loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: same operator, same results bit for bit, but the
+ * reduction partials live in a 2.02 MiB array inside the library (one copy per GPU, held until the process ends) instead
+ * of a caller-provided workspace; the call itself allocates nothing.  Limit: y.channels <= DN_NOALLOC_MAX_CHANNELS (512,
+ * the widest layer of the shipped net), otherwise DN_STATUS_BAD_ARGUMENT.  All calls on one GPU share that array: calls
+ * that overlap on one GPU (different streams or threads) race; calls on one stream are ordered and safe. */
+#define DN_NOALLOC_MAX_CHANNELS 512
+int dn_bn_train_forward_noalloc(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                float* scale, float* shift, int dtype, void* stream);
 /* dn_conv2d followed by nn.MaxPool2d((1,2)) (EncoderBlock, unet_architecture.py:28-42: returns (skip, pooled)) in one
  * kernel: y gets the convolution output (the skip tensor), pooled[n,c,h,w] = max(y[n,c,h,2w], y[n,c,h,2w+1]) with W/2
  * columns.  Kernel sizes (3,5) and (1,3); W even. */
