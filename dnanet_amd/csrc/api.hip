@@ -168,7 +168,8 @@ int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2,
   ConvParams p{};
   p.x = x.base; p.x_planes_total = x.planes_total; p.x_plane0 = x.plane0; p.x_nplanes = xp; p.x_gplanes = 1 << 30; p.x_wmul = 1;
   p.w = packed_w; p.bias = bias2;
-  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = gsize / epr; p.y_wmul = 2;
+  // y_wmul = 2: GEMM plane 2j + k is output column 2w + k of plane j (the epilogue stores the pair together)
+  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 2;
   p.N = N; p.H = H; p.W = Win; p.nchunk = xp; p.cout_pad = 2 * gsize; p.relu = 0;
   flatten_rows(p);
   return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);

@@ -115,7 +115,10 @@ __device__ __forceinline__ void conv_epilogue_head(const ConvParams& p, f32x16_t
 // POOL form: the plain form, plus max over each even/odd column pair (neighbouring lanes; rounding is monotonic, so the
 // max of the fp32 values rounds to the max of the stored ones) through a second scratch (COT/EPR x 512 B per wave) into
 // p.pool -- unet_architecture.py:37 without a second pass over the skip tensor.
-template <typename T, int HT, int COT, int EPI>
+// PAIRS (1x1 GEMMs only): the transposed convolution's output, y_wmul == 2 -- GEMM plane 2j + k is output column 2w + k of
+// output plane j (DN_PACK_CONVT_FWD row order), so the two planes of a pair are stored together: 16 pixels x 64 B = 1 KiB
+// of consecutive bytes per store instruction instead of 32-byte pieces at a 64-byte stride.
+template <typename T, int HT, int COT, int EPI, bool PAIRS = false>
 __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_t (&acc)[HT][COT / 32], unsigned char* scratch,
                                                     float* stat_wave, unsigned char* pool_scratch, int n, int h0, int wbase,
                                                     int cot, int lane) {
@@ -195,6 +198,22 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
             }
           }
         }
+        if (PAIRS && p.y_wmul == 2) {                   // block-uniform
+          static_assert(!PAIRS || (CPP * GPL) % 2 == 0, "a tile holds whole plane pairs");
+#pragma unroll
+          for (int pp = 0; pp < CPP * GPL / 2; ++pp) {
+            const int yplane = ((cot * NCG + ps * CPP) * GPL) / 2 + pp;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const int px = hf * 16 + (lane >> 2), k = (lane >> 1) & 1, pc = lane & 1;
+              const uint4 val = *(const uint4*)(scratch + (2 * pp + k) * 1024 + px * 32 + pc * 16);
+              if (yplane < p.y_nplanes && wbase + px < p.W) {
+                const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow + (long)(wbase + px) * 2 + k;
+                *(uint4*)(yb + rec * 32 + 16 * pc) = val;
+              }
+            }
+          }
+        } else
 #pragma unroll
         for (int pl = 0; pl < CPP * GPL; ++pl) {
           const int vplane = (cot * NCG + ps * CPP) * GPL + pl;
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   float* stat_lds = (float*)(smem_all + 4 * NPL * 1024);            // [wave][COT][2], past every wave's scratch
   unsigned char* pool_lds = smem_all + 4 * NPL * 1024 + 4 * COT * 2 * 4;   // [wave][NPL][512 B]
   if constexpr (EPI == CONV_EPI_HEAD) conv_epilogue_head<T, HT, COT>(p, acc, n, h0, w0 + 32 * wave, lane);
-  else conv_epilogue_store<T, HT, COT, EPI>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
+  else conv_epilogue_store<T, HT, COT, EPI, KH == 1 && KW == 1>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
                                             pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
   if constexpr (STATS) {
     // BatchNorm statistics of this tile: partial[pixel tile][channel][sum, sum of squares] (bn_finalize_kernel's layout)

@@ -148,8 +148,8 @@ __device__ __forceinline__ void pack_element(const float* __restrict__ w, const 
     float v = 0.f;
     if (mode == DN_PACK_VEC) {                 // [rows_pad]
       if (i < cout) v = w[i];
-    } else if (mode == DN_PACK_UP_BIAS) {      // [2][gsize]
-      const int co = (int)(i % gsize);
+    } else if (mode == DN_PACK_UP_BIAS) {      // [2 * gsize] in the row order of DN_PACK_CONVT_FWD
+      const int co = (int)(i / (2 * EPR)) * EPR + (int)(i % EPR);
       if (co < cout) v = w[co];
     } else {                                   // DN_PACK_FIRST: [taps][rows_pad]
       const int co = (int)(i % rows_pad), tap = (int)(i / rows_pad);
@@ -170,9 +170,11 @@ __device__ __forceinline__ void pack_element(const float* __restrict__ w, const 
   } else if (mode == DN_PACK_DGRAD) {        // rows = ci, K = co, taps flipped
     const int ci = row, co = ck * EPR + e;
     if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + (taps - 1 - tap)];
-  } else if (mode == DN_PACK_CONVT_FWD) {    // w: [cin][cout][1][2]; rows = k*gsize + co, K = ci
-    const int k = row / gsize, co = row % gsize, ci = ck * EPR + e;
-    if (k < 2 && co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
+  } else if (mode == DN_PACK_CONVT_FWD) {    // w: [cin][cout][1][2]; rows = [output plane][k][EPR channels], K = ci:
+    // the two output columns of a plane are neighbouring GEMM planes, so one tile holds both and its epilogue writes
+    // whole 64-byte pixel pairs (conv_epilogue_store, PAIRS)
+    const int k = (row / EPR) & 1, co = (row / (2 * EPR)) * EPR + row % EPR, ci = ck * EPR + e;
+    if (co < cout && ci < cin) v = w[((long)ci * cout + co) * 2 + k];
   } else {                                   // DN_PACK_CONVT_DGRAD: rows = ci, K = (k, co) virtual planes
     const int gpl = gsize / EPR;
     const int k = ck / gpl, co = (ck % gpl) * EPR + e, ci = row;

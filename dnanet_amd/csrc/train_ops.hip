@@ -132,14 +132,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned ch
   block_reduce_store<2, PN>(acc, partial, cpad, plane, EPR);
 }
 
-// finalize: mean, invstd, running stats, scale/shift for the apply pass
-__global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count, const float* gamma,
-                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                   float* mean_out, float* invstd_out, float* scale, float* shift) {
-  const int c = blockIdx.x;       // one 256-thread block per channel
-  if (c >= C) { if (threadIdx.x == 0) { scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
-  // With the statistics fused into the convolution there is one partial per conv tile (thousands): every thread keeps
-  // four (sum, sum of squares) pairs in flight, fixed order, fp64 accumulation.
+// Sum of the [nblk][cpad] (sum, sum of squares) partial pairs of channel c over a 256-thread block, fixed order, fp64.
+// With the statistics fused into the convolution there is one partial per conv tile (thousands): every thread keeps four
+// pairs in flight.  The result is valid in thread 0.
+__device__ __forceinline__ void block_sum_pairs(const float* partial, int nblk, int cpad, int c, double& s_out, double& ss_out) {
   const float2* p = (const float2*)partial + c;
   double s = 0.0, ss = 0.0;
   int i = threadIdx.x;
@@ -154,9 +150,14 @@ __global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int
   __shared__ double red[4][2];
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = ss; }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  s = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-  ss = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  s_out = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  ss_out = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+}
+
+// mean, invstd, running statistics, fused scale / shift of one channel from its totals over `count` values
+__device__ __forceinline__ void bn_finalize_channel(int c, double s, double ss, double count, const float* gamma, const float* beta,
+                                                    float* running_mean, float* running_var, float momentum, float eps,
+                                                    float* mean_out, float* invstd_out, float* scale, float* shift) {
   const double mean = s / count;
   double var = ss / count - mean * mean;
   if (var < 0) var = 0;
@@ -171,6 +172,38 @@ __global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
+}
+
+// finalize: mean, invstd, running stats, scale/shift for the apply pass
+__global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                   float* mean_out, float* invstd_out, float* scale, float* shift) {
+  const int c = blockIdx.x;       // one 256-thread block per channel
+  if (c >= C) { if (threadIdx.x == 0) { scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
+  double s, ss;
+  block_sum_pairs(partial, nblk, cpad, c, s, ss);
+  if (threadIdx.x != 0) return;
+  bn_finalize_channel(c, s, ss, count, gamma, beta, running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift);
+}
+
+// ---- synchronised BatchNorm (data parallel, optional): the same two steps with an all-reduce in between ---------------
+// totals[c][2] (fp64) = this rank's sums; the caller sums them over the ranks; the finalize kernels take the global totals
+// and the global count.  One rank: bitwise the same as the kernels above (same summation order, same fp64 arithmetic).
+__global__ void bn_pair_totals_kernel(const float* partial, int nblk, int cpad, int C, double* totals) {
+  const int c = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  if (c < C) block_sum_pairs(partial, nblk, cpad, c, s, ss);
+  if (threadIdx.x == 0) { totals[2 * c] = s; totals[2 * c + 1] = ss; }
+}
+
+__global__ void bn_finalize_totals_kernel(const double* totals, int cpad, int C, double count, const float* gamma, const float* beta,
+                                          float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
+                                          float* invstd_out, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cpad) return;
+  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f; return; }
+  bn_finalize_channel(c, totals[2 * c], totals[2 * c + 1], count, gamma, beta, running_mean, running_var, momentum, eps, mean_out,
+                      invstd_out, scale, shift);
 }
 
 // a = relu(y * scale + shift).  Grid (x, plane, image): a plane of one image is a contiguous run of 16-byte pieces, so the
@@ -292,6 +325,30 @@ __global__ void bn_bwd_finalize_kernel(const float* partial, int nblk, int cpad,
   coef[c] = gamma[c] * invstd[c];            // s
   coef[cpad + c] = (float)(s1 / count);      // mean(dz)
   coef[2 * cpad + c] = (float)(s2 / count);  // mean(dz * xhat)
+}
+
+// synchronised form: local totals -> (all-reduce by the caller) -> coefficients from the global totals.  dgamma / dbeta stay
+// LOCAL sums: the data-parallel gradient all-reduce adds them up like every other parameter gradient.
+__global__ void bn_bwd_pair_totals_kernel(const float* partial, int nblk, int cpad, int C, double* totals) {
+  const int c = blockIdx.x;       // one wave per channel
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    s1 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2);
+    s2 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2 + 1);
+  }
+  if (threadIdx.x == 0) { totals[2 * c] = s1; totals[2 * c + 1] = s2; }
+}
+
+__global__ void bn_bwd_finalize_totals_kernel(const double* local, const double* global, int cpad, int C, double count,
+                                              const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cpad) return;
+  if (c >= C) { coef[c] = 0.f; coef[cpad + c] = 0.f; coef[2 * cpad + c] = 0.f; return; }
+  dbeta[c] = (float)local[2 * c];
+  dgamma[c] = (float)local[2 * c + 1];
+  coef[c] = gamma[c] * invstd[c];
+  coef[cpad + c] = (float)(global[2 * c] / count);
+  coef[2 * cpad + c] = (float)(global[2 * c + 1] / count);
 }
 
 // apply (in place on g): dy = s * (dz - c1 - xhat * c2).  Grid (x, plane, image) as bn_apply_relu_kernel.
@@ -581,7 +638,7 @@ int dn_reduce_blocks(long pixels) { return red_blocks(pixels); }
 static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                                  float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream,
-                                 const dn_tensor* pooled = nullptr);
+                                 const dn_tensor* pooled = nullptr, const double* totals = nullptr, double total_count = 0);
 
 int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
@@ -624,14 +681,19 @@ int dn_bn_train_apply_pool(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, in
 static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                                  float* scale, float* shift, float* partial, int given_nblk, int dtype, void* stream,
-                                 const dn_tensor* pooled) {
-  DN_CHECK_ARG(y.base && a.base && gamma && beta && mean && invstd && scale && shift && partial, "dn_bn_train_forward: null pointer");
+                                 const dn_tensor* pooled, const double* totals, double total_count) {
+  DN_CHECK_ARG(y.base && a.base && gamma && beta && mean && invstd && scale && shift && (partial || totals), "dn_bn_train_forward: null pointer");
   DN_CHECK_ARG(y.channels == a.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_forward: bad shape");
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
   DN_CHECK_ARG(HW * 2 < (1L << 31) && N < 65536 && nplanes < 65536, "dn_bn_train_forward: plane too large for the launch grid");
   const int nblk = given_nblk > 0 ? given_nblk : red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
+  if (totals) {
+    // statistics already summed (over every rank of a data-parallel group): finalize from the global totals and count
+    hipLaunchKernelGGL(bn_finalize_totals_kernel, dim3((cpad + 63) / 64), dim3(64), 0, s, totals, cpad, C, total_count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  } else {
   if (given_nblk <= 0) {
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(bn_stats_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)y.base, y.planes_total, y.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), partial, cpad),
@@ -641,6 +703,7 @@ static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, 
   DN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(256), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  }
   DN_LAUNCH_CHECK();
   const int npieces = (int)(HW * 2);
   const dim3 egrid(std::min((npieces + 1023) / 1024, 64), nplanes, N);   // ~4 pieces per thread
@@ -665,27 +728,86 @@ static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, 
   return DN_OK;
 }
 
+int dn_bn_partial_totals(const float* partial, int ntiles, int C, double* totals, void* stream) {
+  DN_CHECK_ARG(partial && totals && ntiles > 0 && C > 0, "dn_bn_partial_totals: bad argument");
+  const int cpad = dn_channel_pad(C);
+  hipLaunchKernelGGL(bn_pair_totals_kernel, dim3(cpad), dim3(256), 0, (hipStream_t)stream, partial, ntiles, cpad, C, totals);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+int dn_bn_train_apply_totals(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, int H, int W, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                             float* scale, float* shift, const double* totals, double count, int dtype, void* stream) {
+  DN_CHECK_ARG(totals && count >= 1, "dn_bn_train_apply_totals: no totals / bad count");
+  return bn_train_forward_impl(y, a, N, H, W, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                               nullptr, 0, dtype, stream, pooled.base ? &pooled : nullptr, totals, count);
+}
+
+static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                                  const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                                  float* partial, int dtype, void* stream, int phase, double* local_totals,
+                                  const double* global_totals, double count);
+
 int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
                          const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                          float* partial, int dtype, void* stream) {
-  DN_CHECK_ARG(g.base && y.base && scale && shift && gamma && mean && invstd && dgamma && dbeta && coef && partial,
-               "dn_bn_train_backward: null pointer");
+  return bn_train_backward_impl(g, y, scale, shift, N, H, W, gamma, mean, invstd, dgamma, dbeta, coef, partial, dtype, stream, 0,
+                                nullptr, nullptr, 0);
+}
+
+int dn_bn_train_backward_totals(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                                const float* mean, const float* invstd, float* partial, double* totals, int dtype, void* stream) {
+  DN_CHECK_ARG(totals, "dn_bn_train_backward_totals: null pointer");
+  return bn_train_backward_impl(g, y, scale, shift, N, H, W, nullptr, mean, invstd, nullptr, nullptr, nullptr, partial, dtype, stream,
+                                1, totals, nullptr, 0);
+}
+
+int dn_bn_train_backward_apply_totals(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                                      const float* gamma, const float* mean, const float* invstd, const double* local_totals,
+                                      const double* global_totals, double count, float* dgamma, float* dbeta, float* coef,
+                                      int dtype, void* stream) {
+  DN_CHECK_ARG(local_totals && global_totals && count >= 1, "dn_bn_train_backward_apply_totals: no totals / bad count");
+  return bn_train_backward_impl(g, y, scale, shift, N, H, W, gamma, mean, invstd, dgamma, dbeta, coef, nullptr, dtype, stream, 2,
+                                (double*)local_totals, global_totals, count);
+}
+
+// phase 0: reduce + finalize + apply (one device).  phase 1: reduce + per-channel totals only.  phase 2: finalize from
+// (local, global) totals + apply.
+static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                                  const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                                  float* partial, int dtype, void* stream, int phase, double* local_totals,
+                                  const double* global_totals, double count) {
+  DN_CHECK_ARG(g.base && y.base && scale && shift && mean && invstd, "dn_bn_train_backward: null pointer");
+  DN_CHECK_ARG(phase == 2 || partial, "dn_bn_train_backward: no partial workspace");
+  DN_CHECK_ARG(phase == 1 || (gamma && dgamma && dbeta && coef), "dn_bn_train_backward: null pointer");
   DN_CHECK_ARG(g.channels == y.channels && N > 0 && H > 0 && W > 0, "dn_bn_train_backward: bad shape");
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
   DN_CHECK_ARG(HW * 2 < (1L << 31) && N < 65536 && nplanes < 65536, "dn_bn_train_backward: plane too large for the launch grid");
   const int nblk = red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
+  if (phase != 2) {
 #define ARGS_R (const unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)y.base, y.planes_total, y.plane0, \
                scale, shift, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), mean, invstd, partial, cpad
-  DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
-    "dn_bn_train_backward");
+    DN_DISPATCH_T(dtype,
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_R),
+      "dn_bn_train_backward");
 #undef ARGS_R
-  DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma,
-                     invstd, dgamma, dbeta, coef);
+    DN_LAUNCH_CHECK();
+  }
+  if (phase == 1) {
+    hipLaunchKernelGGL(bn_bwd_pair_totals_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, local_totals);
+    DN_LAUNCH_CHECK();
+    return DN_OK;
+  }
+  if (phase == 2)
+    hipLaunchKernelGGL(bn_bwd_finalize_totals_kernel, dim3((cpad + 63) / 64), dim3(64), 0, s, local_totals, global_totals, cpad, C,
+                       count, gamma, invstd, dgamma, dbeta, coef);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma,
+                       invstd, dgamma, dbeta, coef);
   DN_LAUNCH_CHECK();
   const int npieces = (int)(HW * 2);
   const dim3 egrid(std::min((npieces + 1023) / 1024, 64), nplanes, N);

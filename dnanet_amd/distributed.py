@@ -12,7 +12,10 @@ The reference is single-device; the path shards in exactly two ways:
   stream as soon as its segment's gradients are complete, overlapping the rest of backward.
   xGMI is point-to-point (7 links x ~153 GB/s per GPU): the 48.5 MB arena costs ~0.6 ms as a ring
   all-reduce against tens of ms of compute per step, so a handful of large buckets is the right grain.
-  BatchNorm uses per-replica batch statistics (the DDP convention); rank 0's running statistics are saved.
+  BatchNorm uses per-replica batch statistics by default (the DDP convention; rank 0's running statistics are saved).
+  ``sync_bn=True`` all-reduces the per-channel statistics instead -- 2*C doubles per BatchNorm in the forward pass
+  ([sum y, sum y^2]) and in the backward pass ([sum dz, sum dz*xhat]) -- which makes R ranks x N/R profiles compute what
+  one device computes at batch N (the only oracle a data-parallel run has): 36 small all-reduces per step.
 """
 from __future__ import annotations
 
@@ -20,6 +23,32 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def _host_staged(tensor: torch.Tensor, group) -> bool:
+    """A gloo group handed a device tensor (tests: two ranks sharing one GPU; RCCL refuses that): the collective runs on a
+    host copy.  gloo's own device-tensor path (pinned bounce buffers on pool streams, a thread pool) was seen to hang
+    after a few dozen collectives with two processes on one MI355X; RCCL groups never take this route."""
+    return tensor.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def all_reduce_sum(tensor: torch.Tensor, group=None):
+    """In-place sum over the group (synchronous)."""
+    if _host_staged(tensor, group):
+        host = tensor.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        tensor.copy_(host)
+    else:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+
+
+def broadcast(tensor: torch.Tensor, src: int = 0, group=None):
+    if _host_staged(tensor, group):
+        host = tensor.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        tensor.copy_(host)
+    else:
+        dist.broadcast(tensor, src=src, group=group)
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -85,14 +114,23 @@ class ArenaAllReducer:
         self.segments = list(segments)
         self.min_bucket = min_bucket_elems
         self._pending: List[Tuple[int, int]] = []
+        self._deferred: List[Tuple[int, int]] = []
         self._works = []
-        self.stream = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
+        # Overlap with backward (side stream, async launches) only under RCCL, whose collectives all run in issue order on
+        # the group's own stream; a gloo group given device tensors reduces the buckets one after the other in finish(),
+        # through the host (all_reduce_sum).
+        self.overlap = flat_grads.is_cuda and dist.get_backend(group) == "nccl"
+        self.stream = torch.cuda.Stream(device=flat_grads.device) if self.overlap else None
         self._by_name = {n: (a, b) for n, a, b in self.segments}
         self.launched: List[Tuple[int, int]] = []
         self.last_buckets: List[Tuple[int, int]] = []     # the (start, stop) ranges the latest step reduced
 
     def _launch(self, lo: int, hi: int):
         view = self.flat[lo:hi]
+        if self.flat.is_cuda and not self.overlap:
+            self._deferred.append((lo, hi))
+            self.launched.append((lo, hi))
+            return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -115,6 +153,9 @@ class ArenaAllReducer:
         if self._pending:
             self._launch(min(a for a, _ in self._pending), max(b for _, b in self._pending))
             self._pending = []
+        for lo, hi in self._deferred:
+            all_reduce_sum(self.flat[lo:hi], self.group)
+        self._deferred = []
         for w in self._works:
             w.wait()
         if self.stream is not None:
@@ -129,7 +170,7 @@ def all_reduce_dice_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
     """sums = [sum p*t, sum p, sum t, #correct, local loss, ...] -> the same with global sums and the global
     Dice loss 1 - (2I+1)/(P+T+1) in slot 4."""
     out = sums.clone()
-    dist.all_reduce(out[:4], op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(out[:4], group)
     out[4] = 1.0 - (2.0 * out[0] + 1.0) / (out[1] + out[2] + 1.0)
     return out
 
@@ -137,13 +178,15 @@ def all_reduce_dice_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
 class DataParallelTrainer:
     """One data-parallel training step of ``HipUNet`` on this rank's shard of the global batch."""
 
-    def __init__(self, model, optimizer, group=None, min_bucket_elems: int = 1 << 20):
+    def __init__(self, model, optimizer, group=None, min_bucket_elems: int = 1 << 20, sync_bn: bool = False):
         self.model, self.optimizer, self.group = model, optimizer, group
+        self.sync_bn = bool(sync_bn)
+        model.sync_bn = (lambda t: all_reduce_sum(t, group), dist.get_world_size(group)) if sync_bn else None
         self.reducer = ArenaAllReducer(model.flat_grads, module_segments(model.offsets, model.depth, model.flat_grads.numel()), group,
                                        min_bucket_elems)
         # identical initial weights on every rank
-        dist.broadcast(model.flat_params, src=0, group=group)
-        dist.broadcast(model.flat_stats, src=0, group=group)
+        broadcast(model.flat_params, 0, group)
+        broadcast(model.flat_stats, 0, group)
         model._param_epoch += 1
 
     def step(self, x_local: torch.Tensor, t_local: torch.Tensor) -> torch.Tensor:

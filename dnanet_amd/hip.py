@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 import torch
 
@@ -59,6 +59,12 @@ _SIGS = {
                                     _P, _P, _P, _P, _P, c_int, _P]),
     "dn_bn_train_forward_noalloc": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float,
                                             _P, _P, _P, _P, c_int, _P]),
+    "dn_bn_partial_totals": (c_int, [_P, c_int, c_int, _P, _P]),
+    "dn_bn_train_apply_totals": (c_int, [DnTensor, DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float,
+                                         _P, _P, _P, _P, _P, c_double, c_int, _P]),
+    "dn_bn_train_backward_totals": (c_int, [DnTensor, DnTensor, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "dn_bn_train_backward_apply_totals": (c_int, [DnTensor, DnTensor, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_double,
+                                                  _P, _P, _P, c_int, _P]),
     "dn_bn_train_backward": (c_int, [DnTensor, DnTensor, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "dn_maxpool_1x2_backward": (c_int, [DnTensor, DnTensor, DnTensor, DnTensor, c_int, c_int, c_int, c_int, _P]),
     "dn_head_1x1_backward": (c_int, [_P, DnTensor, _P, DnTensor, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -139,6 +145,17 @@ def partial_floats(c: int) -> int:
 def first_wgrad_partial_floats(cout: int, kh: int, kw: int, blocks: int = 512) -> int:
     """Capacity ``dn_conv_first_wgrad`` needs in its ``partial`` workspace (``blocks`` = its largest grid)."""
     return blocks * kh * kw * channel_pad(cout)
+
+
+def up_bias2(b: torch.Tensor, dtype: int) -> torch.Tensor:
+    """ConvTranspose2d bias [cout] as ``dn_conv_transpose_1x2`` takes it: 2 * channel_pad(cout) floats in the row order of the
+    DN_PACK_CONVT_FWD image, [output plane][output column k][channels of the plane] (zero past cout)."""
+    gs, e = channel_pad(b.numel()), epr(dtype)
+    rows = torch.arange(2 * gs, device=b.device)
+    co = (rows // (2 * e)) * e + rows % e
+    padded = torch.zeros(gs, dtype=torch.float32, device=b.device)
+    padded[:b.numel()] = b.reshape(-1)
+    return padded[co].contiguous()
 
 
 def planes(c: int, dtype: int) -> int:

@@ -280,7 +280,11 @@ class DNANet_UNet(TrainableModel):
             raise RuntimeError("data_parallel=True needs an initialised torch.distributed process group")
         if dp and batch_size % group_size:
             raise ValueError(f"batch_size {batch_size} is not divisible by the {group_size} ranks of the process group")
-        self._dp = {"trainer": None} if dp else None
+        # ``sync_bn=True`` (data parallel only): BatchNorm statistics of the global batch instead of per-replica ones
+        sync_bn = bool(kwargs.pop("sync_bn", False))
+        if sync_bn and not dp:
+            raise ValueError("sync_bn needs data_parallel training (an initialised process group)")
+        self._dp = {"trainer": None, "sync_bn": sync_bn} if dp else None
         use_graph = kwargs.pop("hip_graph", None)
         if use_graph is None:
             use_graph = batch_size <= 64 and not dp
@@ -295,6 +299,7 @@ class DNANet_UNet(TrainableModel):
             self.release_resident()
             self._graph = {"enabled": False, "step": None, "warm": False}
             self._dp = None
+            self._model.sync_bn = None
         if writer:
             writer.close()
         if save_best:
@@ -402,8 +407,8 @@ class DNANet_UNet(TrainableModel):
         if train and self._dp is not None:
             # BatchNorm running statistics are per replica: continue from rank 0's, so that validation losses -- and with
             # them early stopping and best-model decisions -- are identical on every rank
-            import torch.distributed as dist
-            dist.broadcast(self._model.flat_stats, src=0)
+            from .distributed import broadcast
+            broadcast(self._model.flat_stats, 0)
             self._model._param_epoch += 1
         return epoch_loss
 
@@ -419,7 +424,7 @@ class DNANet_UNet(TrainableModel):
         local = batch[rank * per:(rank + 1) * per]
         cfg = self._dp
         if cfg["trainer"] is None or cfg["trainer"].optimizer is not optimizer:
-            cfg["trainer"] = DataParallelTrainer(self._model, optimizer)
+            cfg["trainer"] = DataParallelTrainer(self._model, optimizer, sync_bn=cfg.get("sync_bn", False))
         inputs, y_true = self.get_inputs(local), self.get_targets(local)
         sums = cfg["trainer"].step(inputs, y_true)
         return _Loss(self._model, sums, inputs.numel() * world, metrics)

@@ -54,6 +54,9 @@ class HipUNet(ParameterTree):
         self._saved = None
         self._ws = None
         self.wgrad_workspace_bytes = 256 << 20
+        # synchronised BatchNorm (data parallel, optional): a (all_reduce(tensor), world_size) pair set by
+        # DataParallelTrainer(sync_bn=True); None = per-replica batch statistics
+        self.sync_bn = None
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -104,11 +107,7 @@ class HipUNet(ParameterTree):
         return out
 
     def _up_bias2(self, b: torch.Tensor) -> torch.Tensor:
-        gs = hip.channel_pad(b.numel())
-        out = torch.zeros(2 * gs, dtype=torch.float32, device=self.device)
-        out[:b.numel()] = b
-        out[gs:gs + b.numel()] = b
-        return out
+        return hip.up_bias2(b, self.dtype)
 
     # ------------------------------------------------------------------------------------------
     # eval-mode (BatchNorm folded into the packed weights)
@@ -365,13 +364,25 @@ class HipUNet(ParameterTree):
                 hip.check(hip.lib.dn_conv2d_stats(src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, kh, kw,
                                                   self.dtype, hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles),
                                                   hip.stream_ptr()))
-            if pooled is not None:
+            if self.sync_bn is not None:
+                # batch statistics of the GLOBAL batch: this rank's per-channel totals (fp64) are summed over the group
+                all_reduce, world = self.sync_bn
+                totals = torch.empty(2 * cp, dtype=torch.float64, device=self.device)
+                hip.check(hip.lib.dn_bn_partial_totals(hip.ptr(ws["bnstat"]), ntiles.value, u.cout, hip.ptr(totals), hip.stream_ptr()))
+                all_reduce(totals)
+                hip.check(hip.lib.dn_bn_train_apply_totals(y.ref(u.cout), dst, pooled if pooled is not None else hip.DnTensor(None, 0, 0, 0),
+                                                           n, h, w, *bn_args, hip.ptr(totals), float(n * h * w * world), self.dtype,
+                                                           hip.stream_ptr()))
+            elif pooled is not None:
                 hip.check(hip.lib.dn_bn_train_apply_pool(y.ref(u.cout), dst, pooled, n, h, w, *bn_args, hip.ptr(ws["bnstat"]),
                                                          ntiles.value, self.dtype, hip.stream_ptr()))
             else:
                 hip.check(hip.lib.dn_bn_train_apply(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["bnstat"]), ntiles.value,
                                                     self.dtype, hip.stream_ptr()))
         else:
+            if self.sync_bn is not None:
+                raise NotImplementedError("synchronised BatchNorm needs the fused-statistics convolutions: kernel sizes (3,5) / "
+                                          "(1,3), and no per-launch profiling")
             self._conv(u, cache[u.conv], raw_x if u.cin == 1 else src, y.ref(u.cout), n, h, w, relu=0)
             hip.check(hip.lib.dn_bn_train_forward(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["partial"]), self.dtype,
                                                   hip.stream_ptr()))
@@ -452,11 +463,25 @@ class HipUNet(ParameterTree):
         ws, cache, sv = self._workspace(), self._train_cache, self._saved[u.conv]
         n, h, w = sv["n"], sv["h"], sv["w"]
         kh, kw = self.kernel_size
-        hip.check(hip.lib.dn_bn_train_backward(
-            g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
-            hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(sv["mean"]),
-            hip.ptr(sv["invstd"]), hip.ptr(self.grad(u.bn + ".weight")), hip.ptr(self.grad(u.bn + ".bias")),
-            hip.ptr(ws["coef"]), hip.ptr(ws["partial"]), self.dtype, hip.stream_ptr()))
+        if self.sync_bn is not None:
+            all_reduce, world = self.sync_bn
+            local = torch.empty(2 * hip.channel_pad(u.cout), dtype=torch.float64, device=self.device)
+            hip.check(hip.lib.dn_bn_train_backward_totals(g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
+                                                          hip.ptr(sv["mean"]), hip.ptr(sv["invstd"]), hip.ptr(ws["partial"]),
+                                                          hip.ptr(local), self.dtype, hip.stream_ptr()))
+            total = local.clone()
+            all_reduce(total)
+            hip.check(hip.lib.dn_bn_train_backward_apply_totals(
+                g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w, hip.ptr(self.tensor(u.bn + ".weight")),
+                hip.ptr(sv["mean"]), hip.ptr(sv["invstd"]), hip.ptr(local), hip.ptr(total), float(n * h * w * world),
+                hip.ptr(self.grad(u.bn + ".weight")), hip.ptr(self.grad(u.bn + ".bias")), hip.ptr(ws["coef"]), self.dtype,
+                hip.stream_ptr()))
+        else:
+            hip.check(hip.lib.dn_bn_train_backward(
+                g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
+                hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(sv["mean"]),
+                hip.ptr(sv["invstd"]), hip.ptr(self.grad(u.bn + ".weight")), hip.ptr(self.grad(u.bn + ".bias")),
+                hip.ptr(ws["coef"]), hip.ptr(ws["partial"]), self.dtype, hip.stream_ptr()))
         # the conv bias feeds a BatchNorm: its gradient is identically zero, the arena entry stays 0
         if u.cin == 1:
             hip.check(hip.lib.dn_conv_first_wgrad(hip.ptr(self._saved["x"]), g, hip.ptr(self.grad(u.conv + ".weight")),

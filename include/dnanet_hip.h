@@ -171,6 +171,28 @@ int dn_bn_train_apply_pool(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, in
 int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
                          const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                          float* partial, int dtype, void* stream);
+/* ---- synchronised BatchNorm (optional, data parallel; NO COUNTERPART IN THE REFERENCE, which is single-device: this is what
+ * makes "R ranks x N/R profiles" compute the batch statistics -- hence the results -- of one device at batch N, the only
+ * oracle a data-parallel run has).  Forward: dn_conv2d_stats / dn_conv_first_stats -> dn_bn_partial_totals ->
+ * the caller sums `totals` over the ranks (2 * dn_channel_pad(C) doubles) -> dn_bn_train_apply_totals with the global
+ * count.  Backward: dn_bn_train_backward_totals -> sum over the ranks -> dn_bn_train_backward_apply_totals.  With one
+ * rank the results are bitwise those of dn_bn_train_apply / dn_bn_train_backward. */
+/* totals[c][2] = fixed-order fp64 sums of the [ntiles][dn_channel_pad(C)][2] partials (zero for c >= C). */
+int dn_bn_partial_totals(const float* partial, int ntiles, int C, double* totals, void* stream);
+/* dn_bn_train_apply(_pool) from summed totals: mean / biased variance over `count` values (the GLOBAL batch), running-stat
+ * update with the unbiased variance of that count; pooled.base may be null. */
+int dn_bn_train_apply_totals(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, int H, int W, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                             float* scale, float* shift, const double* totals, double count, int dtype, void* stream);
+/* First half of dn_bn_train_backward: totals[c][2] = { sum dz, sum dz * xhat } of this rank (g is not modified). */
+int dn_bn_train_backward_totals(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                                const float* mean, const float* invstd, float* partial, double* totals, int dtype, void* stream);
+/* Second half: g -> dL/dy with the batch means taken from global_totals / count; dgamma / dbeta are this rank's sums
+ * (local_totals), which the data-parallel gradient all-reduce adds up like every other parameter gradient. */
+int dn_bn_train_backward_apply_totals(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                                      const float* gamma, const float* mean, const float* invstd, const double* local_totals,
+                                      const double* global_totals, double count, float* dgamma, float* dbeta, float* coef,
+                                      int dtype, void* stream);
 /* Backward of nn.MaxPool2d((1,2)) (unet_architecture.py:37) fused with the skip-connection add:
  * g = dskip (nullable .base) + route(dpool) to the first maximal element of every pair of x. */
 int dn_maxpool_1x2_backward(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, int N, int H, int Wout, int dtype,

@@ -11,7 +11,7 @@ for cin, cout, win in [(512, 256, 256), (256, 128, 512), (128, 64, 1024), (64, 3
     nb = hip.lib.dn_packed_weight_bytes(cout, cin, 1, 2, hip.PACK_CONVT_FWD, dtype)
     pk = torch.empty(nb, dtype=torch.uint8, device=dev)
     hip.check(hip.lib.dn_pack_weight(hip.ptr(w), None, hip.ptr(pk), cout, cin, 1, 2, hip.PACK_CONVT_FWD, dtype, hip.stream_ptr()))
-    b2 = torch.zeros(2 * hip.channel_pad(cout), device=dev)
+    b2 = hip.up_bias2(torch.zeros(cout, device=dev), dtype)
     def run():
         hip.check(hip.lib.dn_conv_transpose_1x2(x.ref(cin), hip.ptr(pk), hip.ptr(b2), y.ref(cout, 0), n, h, win, dtype, hip.stream_ptr()))
     run(); torch.cuda.synchronize()

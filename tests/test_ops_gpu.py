@@ -290,10 +290,7 @@ def test_conv_transpose(gpu_device, case, dtype):
     ref = F.conv_transpose2d(x, wt, b, stride=(1, 2))
     xb = hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype)
     packed = _pack(hip, wt, None, hip.PACK_CONVT_FWD, dtype, gpu_device)
-    gs = hip.channel_pad(cout)
-    bias2 = torch.zeros(2 * gs, device=gpu_device)
-    bias2[:cout] = b.to(gpu_device)
-    bias2[gs:gs + cout] = b.to(gpu_device)
+    bias2 = hip.up_bias2(b.to(gpu_device), dtype)
     # output lands in the first half of a concat buffer (up first, skip second)
     p = hip.planes(cout, dtype)
     yb = hip.PlaneBuffer(n, 2 * p, h, 2 * win, dtype, gpu_device, zero=True)
@@ -647,7 +644,7 @@ def test_pack_batched_equals_single_packs(gpu_device, dtype):
             if mode == hip.PACK_VEC:
                 want = torch.zeros(cp); want[:cout] = w.cpu()
             elif mode == hip.PACK_UP_BIAS:
-                want = torch.zeros(2, cp); want[:, :cout] = w.cpu(); want = want.reshape(-1)
+                want = hip.up_bias2(w, dtype).cpu()       # [output plane][k][channels of the plane]
             else:
                 want = torch.zeros(taps, cp); want[:, :cout] = w.cpu().reshape(cout, taps).t(); want = want.reshape(-1)
             assert torch.equal(got, want), mode

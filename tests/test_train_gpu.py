@@ -10,11 +10,19 @@ pytestmark = pytest.mark.gpu
 # fp32: max |g - g_ref| / max |g_ref| per tensor.  bf16: activations and gradients are stored with 8
 # significant bits, and ReLU masks / max-pool routing of near-tied values flip, so single elements move
 # by O(1); the bf16 bar is on the relative L2 error of every gradient tensor instead.
-# Every bf16 kernel is separately checked bit-exact on integer data in test_ops_gpu.py; here the bf16 bar
-# is coarse on purpose (toy nets with 8 filters and BN over a few hundred values are noise dominated).
-GRAD_TOL = {"fp32": 2e-3, "bf16": 1.0}
-BF16_MIN_COSINE = 0.9
-LOSS_TOL = {"fp32": 2e-5, "bf16": 2e-2}
+# Every bf16 kernel is separately checked bit-exact on integer data in test_ops_gpu.py.  The bf16 bounds below are the
+# errors measured on MI355X per fixture (tests/tools/diag_bf16_bounds.py, round 2: worst / median per-tensor relative
+# L2 0.24 / 0.09, 0.39 / 0.10, 0.31 / 0.17, 0.66 / 0.30; cosine of the whole gradient 0.998, 0.998, 0.992, 0.947; loss
+# error < 7e-5) with a 1.3x margin: toy nets with 8 filters whose BatchNorms see a few hundred values are noise dominated,
+# the deep 1x3 one most; the shipped size is held to cosine > 0.98 in test_fullsize_gpu.py.
+GRAD_TOL = {"fp32": 2e-3}
+BF16_BOUNDS = {                      # fixture -> (worst tensor rel-L2, median tensor rel-L2, min cosine of the whole gradient)
+    "g_d2_k35_f8_h5_w64": (0.32, 0.13, 0.997),
+    "g_d2_k35_f8_h6_w96": (0.52, 0.14, 0.997),
+    "g_d3_k35_f8_h5_w128": (0.40, 0.23, 0.989),
+    "g_d4_k13_f8_h5_w256": (0.86, 0.40, 0.93),
+}
+LOSS_TOL = {"fp32": 2e-5, "bf16": 2e-4}
 
 
 def _train_names():
@@ -38,12 +46,14 @@ def test_train_steps_vs_reference_fixture(gpu_device, name, dtype):
         sums = m.dice_forward(logits, t)
         m.backward()
         loss = float(sums[4])
-        assert abs(loss - float(g[f"step{s}/loss"])) < LOSS_TOL[dtype], (s, loss, float(g[f"step{s}/loss"]))
+        # later bf16 steps start from bf16-trained parameters: the trajectories drift apart, only step 0 is like for like
+        ltol = LOSS_TOL[dtype] if (dtype == "fp32" or s == 0) else 2e-2
+        assert abs(loss - float(g[f"step{s}/loss"])) < ltol, (s, loss, float(g[f"step{s}/loss"]))
         ref = torch.from_numpy(g[f"step{s}/logits"])
         if s == 0:
             err = float((logits.cpu() - ref).abs().max() / ref.abs().max())
             assert err < (1e-4 if dtype == "fp32" else 6e-2), err
-            worst = ("", 0.0)
+            worst, per_tensor = ("", 0.0), []
             for k, gr in g["grad0"].items():
                 scale = float(gr.abs().max()) + 1e-20
                 if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
@@ -52,17 +62,22 @@ def test_train_steps_vs_reference_fixture(gpu_device, name, dtype):
                     if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
                         continue
                     e = float((m.grad(k).cpu() - gr).norm() / (gr.norm() + 1e-20))
+                    per_tensor.append(e)
                 else:
                     e = float((m.grad(k).cpu() - gr).abs().max()) / scale
                 if e > worst[1]:
                     worst = (k, e)
-            assert worst[1] < GRAD_TOL[dtype], worst
+            if dtype == "fp32":
+                assert worst[1] < GRAD_TOL[dtype], worst
             if dtype == "bf16":
+                worst_tol, median_tol, min_cos = BF16_BOUNDS[name]
+                assert worst[1] < worst_tol, worst
+                assert sorted(per_tensor)[len(per_tensor) // 2] < median_tol, sorted(per_tensor)[len(per_tensor) // 2]
                 keys = [k for k in g["grad0"] if not (k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"))]
                 a = torch.cat([m.grad(k).cpu().flatten() for k in keys])
                 b = torch.cat([g["grad0"][k].flatten() for k in keys])
                 cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-                assert cos > BF16_MIN_COSINE, cos
+                assert cos > min_cos, cos
         opt.step()
         opt.zero_grad()
     if dtype == "fp32":

@@ -9,7 +9,7 @@ from conftest import golden_names, load_golden
 pytestmark = pytest.mark.gpu
 
 # stated tolerances on logits, relative to max|logit| of the case
-TOL = {"fp32": 2e-5, "bf16": 4e-2}
+TOL = {"fp32": 2e-5, "bf16": 2e-2}      # measured: fp32 < 1e-6, bf16 < 1.1e-2 on the fixtures, < 5e-3 at the shipped size
 
 
 def _model(g, dtype, dev):
@@ -33,13 +33,14 @@ def test_logits_vs_reference_fixture(gpu_device, name, dtype):
     err = float((logits.cpu() - ref).abs().max()) / scale
     assert err < TOL[dtype], f"{name} {dtype}: max rel err {err:.3e}"
     assert torch.allclose(probs.cpu(), torch.sigmoid(logits.cpu()), atol=1e-6)
-    # segmentation masks (sigmoid >= 0.5, allele_callers.py:80): identical in fp32 mode except
-    # where the reference logit itself sits within the tolerance of the threshold
+    # segmentation masks (sigmoid >= 0.5, allele_callers.py:80): identical in fp32 mode (measured: 0 differing pixels on
+    # every fixture, the two real RD profiles included); in bf16 mode only where the reference logit itself sits within
+    # the tolerance of the threshold
     mask, ref_mask = probs.cpu() >= 0.5, torch.sigmoid(ref) >= 0.5
     decided = ref.abs() > TOL[dtype] * scale
     assert torch.equal(mask[decided], ref_mask[decided])
     if dtype == "fp32":
-        assert int((mask != ref_mask).sum()) <= 2
+        assert torch.equal(mask, ref_mask)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
