@@ -16,6 +16,7 @@ import yaml
 
 from functools import partial
 
+from .caching import ArrowCacheDataset
 from .data import ArrayDataset, NpyDirDataset, SyntheticDataset
 from .metrics import METRICS
 from .model import DNANet_UNet, Model
@@ -23,7 +24,7 @@ from .model import DNANet_UNet, Model
 MODELS = {"model": {"unet": DNANet_UNet}}
 # The reference registers its .hid reader here (``config_io.py:28``); parsing .hid files is outside the hot path, so
 # the datasets of this build are array-backed.  A reference ``HIDDataset`` can be passed to the model API directly.
-DATASETS = {"dataset": {"npy": NpyDirDataset, "synthetic": SyntheticDataset}}
+DATASETS = {"dataset": {"npy": NpyDirDataset, "synthetic": SyntheticDataset, "arrow_cache": ArrowCacheDataset}}
 
 
 def get_config_path(name: str, kind: Optional[str] = None, root="." ) -> Path:

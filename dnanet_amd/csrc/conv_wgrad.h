@@ -30,6 +30,7 @@ struct WgradParams {
   int co_pad, ci_pad;
   int nsplit, nstrips, ntw, nth;
   int skip_halo;            // leave out the products with zero halo rows (set by the launcher; tuning switch)
+  int xcd_split;            // 1: block -> (tile, split) map that gives every XCD its own K ranges (set by the launcher)
 };
 
 template <typename T> struct WgTraits;
@@ -82,11 +83,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   const int l31 = lane & 31, half = lane >> 5;
   const int n_cit = p.ci_pad / CI_T, n_cot = p.co_pad / CO_T;
   // tiles are the fast block index: blocks that run together walk the SAME strips (same split) for different
-  // (co, ci) tiles, so a strip is fetched from HBM about once per XCD L2 instead of once per tile
-  int b = blockIdx.x;
-  const int cit = b % n_cit; b /= n_cit;
-  const int cot = b % n_cot;
-  const int split = b / n_cot;
+  // (co, ci) tiles, so a strip is fetched from HBM about once per XCD L2 instead of once per tile.  Blocks b and b + 8
+  // share an XCD (and its L2): with xcd_split the split index is tied to the XCD (split = 8 * group + b % 8), so that an
+  // XCD walks its own K ranges for ALL tiles and no strip is fetched by more than one XCD -- measured before: 2 x FETCH_SIZE
+  // = 2.5 GB per launch against 0.8 GB of operands, dY being pulled into all eight L2s.
+  int cit, cot, split;
+  if (p.xcd_split) {
+    const int j = blockIdx.x >> 3, tiles = n_cit * n_cot;
+    const int t = j % tiles;
+    cit = t % n_cit; cot = t / n_cit;
+    split = (j / tiles) * 8 + (blockIdx.x & 7);
+    if (split >= p.nsplit) return;          // whole block: the grid is padded to a multiple of 8 splits
+  } else {
+    int b = blockIdx.x;
+    cit = b % n_cit; b /= n_cit;
+    cot = b % n_cot;
+    split = b / n_cot;
+  }
 
   f32x16_t acc[WT][NCOG][NCIG];
 #pragma unroll
@@ -378,13 +391,22 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   // >= 2048 pixels per block: every slab costs a round trip through HBM
   nsplit = std::min<long>(nsplit, std::max<long>(1, (long)p.nstrips * HT * SW / 2048));
   nsplit = std::min<long>(nsplit, slab_bytes / per_slab);
+  // splits tied to XCDs need a multiple of 8 of them (else some XCDs would idle): round up when the workspace allows
+  bool xcd = !dn_tune().wgrad_no_xcd;
+  if (xcd && nsplit % 8) {
+    const long up = (nsplit + 7) / 8 * 8;
+    if (up <= slab_bytes / per_slab && up <= std::max<long>(1, (long)p.nstrips * HT * SW / 1024)) nsplit = up; else xcd = false;
+  }
   if (nsplit >= p.nth) nsplit -= nsplit % p.nth;   // blocks of one height in the image (halo-row skipping)
+  if (nsplit % 8) xcd = false;
   if (nsplit < 1) return dn_set_error(DN_ERR_ARG, "conv_wgrad: workspace of %ld bytes is smaller than one partial slab (%ld)",
                                       slab_bytes, per_slab);
   p.skip_halo = dn_tune().wgrad_noskip == 2 ? 2 : dn_tune().wgrad_noskip == 1 ? 0 : 1;
   p.nsplit = (int)nsplit;
+  p.xcd_split = xcd ? 1 : 0;
   *nslab_out = (int)nsplit * (KSPLIT ? 4 : 1);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, HT>), dim3((unsigned)(tiles * nsplit)), dim3(256), 0, stream, p);
+  const long grid = p.xcd_split ? tiles * ((nsplit + 7) / 8 * 8) : tiles * nsplit;
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, HT>), dim3((unsigned)grid), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

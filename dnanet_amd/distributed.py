@@ -58,29 +58,42 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def predict_batch_sharded(model, images: Sequence, group=None, dst: int = 0):
+def predict_batch_sharded(model, images: Sequence, group=None, dst: int = 0, gather_images: bool = True):
     """``model.predict_batch`` over one node's GPUs (inference): every rank predicts its contiguous shard of
-    ``images`` -- allele calling included, so only a few hundred bytes of calls plus the probability map per profile
-    leave the rank -- and rank ``dst`` receives the complete list in the order of ``images`` (the other ranks get None).
-    No collective on the data path; the ordered gather is one ``gather_object`` (use a gloo group for it: the payload
-    is host objects)."""
+    ``images`` -- allele calling included, so the product of the path (called alleles, pixel counts) is a few hundred
+    bytes per profile -- and rank ``dst`` receives the complete list in the order of ``images`` (the other ranks get
+    None).  No collective on the data path; the ordered gather is one ``gather_object`` (use a gloo group for it: the
+    payload is host objects).  A shard's probability maps travel as ONE stacked float32 array (a single buffer, not a
+    pickled object per profile); ``gather_images=False`` leaves them on their ranks altogether (``Prediction.image`` is
+    then None on ``dst``) for callers that only want the calls and metrics: at 256 profiles per GPU the maps are 20 MB per
+    rank, the rest a few hundred kB."""
+    import numpy as np
+    from .prediction import Prediction
     images = list(images)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     start, stop = shard_range(len(images), rank, world)
     local = list(model.predict_batch(images[start:stop])) if stop > start else []
-    for p in local:                       # the device pixel counts are tagged with this rank's image objects
-        tag = getattr(p, "_pixel_counts", None)
-        if tag is not None:
-            p._pixel_counts = (None,) + tuple(tag[1:])
+    maps = None
+    if gather_images and local and all(isinstance(p.image, np.ndarray) and p.image.shape == local[0].image.shape for p in local):
+        maps = np.stack([p.image for p in local])
+    payload = {"maps": maps,
+               "items": [(None if maps is not None or not gather_images else p.image, p.meta, getattr(p, "classification", None),
+                          tuple(getattr(p, "_pixel_counts", ())[1:]) or None) for p in local]}
     parts = [None] * world if rank == dst else None
-    dist.gather_object(local, parts, dst=dst, group=group)
+    dist.gather_object(payload, parts, dst=dst, group=group)
     if rank != dst:
         return None
-    out = [p for part in parts for p in part]
-    for image, p in zip(images, out):
-        tag = getattr(p, "_pixel_counts", None)
-        if tag is not None:
-            p._pixel_counts = (id(image),) + tuple(tag[1:])
+    out = []
+    for part in parts:
+        for i, (image, meta, classification, counts) in enumerate(part["items"]):
+            if part["maps"] is not None:
+                image = part["maps"][i]
+            pred = Prediction(image=image, meta=meta)
+            if classification is not None:
+                pred.classification = classification
+            if counts:
+                pred._pixel_counts = (id(images[len(out)]),) + tuple(counts)   # device pixel counts are tagged with the image object
+            out.append(pred)
     return out
 
 

@@ -1,12 +1,14 @@
 #!/bin/bash
 # rocprofv3 passes over bench.py: kernel stats (inference only, then with the training leg), then HBM fetch / write
-# counters in runs of their own.  Results under gpurun_out/; scratch/make_profiles.py turns them into profiles/.
+# counters in runs of their own (with the training leg, so the training kernels have traffic figures too).
+# Results under gpurun_out/; scratch/make_profiles.py turns them into profiles/.
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_infer -o p --output-format csv -- python3 $R/bench.py --steps 10 --no-cpu-baseline --no-train > $R/gpurun_out/prof_infer_bench.log 2>&1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_full -o p --output-format csv -- python3 $R/bench.py --steps 10 --no-cpu-baseline > $R/gpurun_out/prof_full_bench.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > $R/gpurun_out/pmc_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > $R/gpurun_out/pmc_write.log 2>&1
+B="--no-cpu-baseline --no-legs"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_infer -o p --output-format csv -- python3 $R/bench.py --steps 10 $B --no-train > $R/gpurun_out/prof_infer_bench.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_full -o p --output-format csv -- python3 $R/bench.py --steps 10 $B > $R/gpurun_out/prof_full_bench.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 $B > $R/gpurun_out/pmc_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 $B > $R/gpurun_out/pmc_write.log 2>&1
 grep -h '"metric"' $R/gpurun_out/prof_infer_bench.log | tail -1
 grep -h '"metric"' $R/gpurun_out/prof_full_bench.log | tail -1

@@ -107,6 +107,10 @@ def _sharded_predict_worker(rank, world, port, out_path):
         open(out_path, "w").write("ok")
     else:
         assert got is None
+    lean = predict_batch_sharded(Stub(), images, gather_images=False)    # calls / counts only: the maps stay on their ranks
+    if rank == 0:
+        assert all(p.image is None for p in lean) and [p.meta["original_image_path"] for p in lean] == [f"p{i}" for i in range(7)]
+        assert all(p._pixel_counts[2][0] == i for i, p in enumerate(lean))
     empty = predict_batch_sharded(Stub(), images[:1])          # fewer images than ranks: rank 1's shard is empty
     assert (len(empty) == 1) if rank == 0 else empty is None
     dist.destroy_process_group()
