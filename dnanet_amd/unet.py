@@ -57,6 +57,11 @@ class HipUNet(ParameterTree):
         # synchronised BatchNorm (data parallel, optional): a (all_reduce(tensor), world_size) pair set by
         # DataParallelTrainer(sync_bn=True); None = per-replica batch statistics
         self.sync_bn = None
+        # Backward runs the weight gradients on a second HIP stream: they are off the critical path (nothing in the
+        # backward chain reads dW), MFMA-bound, and overlap the HBM-bound BatchNorm / pooling passes of the following
+        # units on the main stream.  DN_TUNE_NO_WGRAD_STREAM=1 keeps everything on one stream (A/B switch).
+        self.overlap_wgrad = self.flat_params.is_cuda and not os.environ.get("DN_TUNE_NO_WGRAD_STREAM")
+        self._wgrad_stream = None
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -458,6 +463,41 @@ class HipUNet(ParameterTree):
             self._saved["targets"], self._saved["sums"] = targets, sums
         return sums
 
+    def _side(self):
+        """The weight-gradient stream of this backward pass, or None (single stream: profiling, switch).  Under HIP-graph
+        capture the side stream forks from / joins the capturing stream, so the graph gets the same parallel branch."""
+        if not self.overlap_wgrad or self.profile is not None or (torch.cuda.is_current_stream_capturing() and
+                                                                   os.environ.get("DN_TUNE_NO_GRAPH_FORK")):
+            return None
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+        return self._wgrad_stream
+
+    def _launch_wgrad(self, launch, *refs):
+        """``launch()`` on the weight-gradient stream, ordered after everything queued on the current stream so far.
+        ``refs``: the plane-record tensors it reads -- the allocator must not hand their memory to a later main-stream
+        allocation while the side stream still reads them."""
+        side = self._side()
+        if side is None:
+            launch()
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            launch()
+        for r in refs:
+            r._owner.data.record_stream(side)
+
+    def _segment_done(self, segment_hook, name):
+        """Tell a data-parallel reducer that the gradients of ``name`` are final: on a stream that is ordered after both the
+        main stream's and the weight-gradient stream's work so far."""
+        side = self._side()
+        if side is None:
+            segment_hook(name)
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            segment_hook(name)
+
     def _unit_backward(self, u: ConvUnit, g, want_dgrad: bool):
         """g: dL/d(output activation) in a buffer (overwritten with dL/dy). Returns dL/d(input) ref."""
         ws, cache, sv = self._workspace(), self._train_cache, self._saved[u.conv]
@@ -488,8 +528,9 @@ class HipUNet(ParameterTree):
                                                   hip.ptr(ws["partial"]), ws["partial"].numel(), n, h, w, kh, kw, self.dtype,
                                                   hip.stream_ptr()))
             return None
-        hip.check(hip.lib.dn_conv2d_wgrad(g, sv["src"], hip.ptr(self.grad(u.conv + ".weight")), hip.ptr(ws["wgrad"]),
-                                          ws["wgrad"].numel(), n, h, w, kh, kw, u.cin, u.split, self.dtype, hip.stream_ptr()))
+        self._launch_wgrad(lambda: hip.check(hip.lib.dn_conv2d_wgrad(
+            g, sv["src"], hip.ptr(self.grad(u.conv + ".weight")), hip.ptr(ws["wgrad"]), ws["wgrad"].numel(), n, h, w, kh, kw,
+            u.cin, u.split, self.dtype, hip.stream_ptr())), g, sv["src"])
         if not want_dgrad:
             return None
         cin_stored = sv["src"].channels
@@ -521,7 +562,7 @@ class HipUNet(ParameterTree):
                                                hip.ptr(self.grad("outputs.weight")), hip.ptr(self.grad("outputs.bias")),
                                                hip.ptr(ws["partial"]), n, h, w, dt, hip.stream_ptr()))
         if segment_hook:
-            segment_hook("head")
+            self._segment_done(segment_hook, "head")
         gcat = [None] * depth
         cur = g
         for i in reversed(range(depth)):
@@ -532,8 +573,9 @@ class HipUNet(ParameterTree):
             d_up = gcat[l].ref(c[l], 0)
             upn = f"decoders.{i}.up"
             xin = S[f"up{i}_in"]
-            hip.check(hip.lib.dn_conv_transpose_1x2_wgrad(d_up, xin, hip.ptr(self.grad(upn + ".weight")), hip.ptr(ws["wgrad"]),
-                                                          ws["wgrad"].numel(), n, h, wl[l + 1], dt, hip.stream_ptr()))
+            self._launch_wgrad(lambda: hip.check(hip.lib.dn_conv_transpose_1x2_wgrad(
+                d_up, xin, hip.ptr(self.grad(upn + ".weight")), hip.ptr(ws["wgrad"]), ws["wgrad"].numel(), n, h, wl[l + 1], dt,
+                hip.stream_ptr())), d_up, xin)
             hip.check(hip.lib.dn_channel_sum(d_up, hip.ptr(self.grad(upn + ".bias")), hip.ptr(ws["partial"]), n, h, wl[l], dt,
                                              hip.stream_ptr()))
             gx = PlaneBuffer(n, self._pp(c[l + 1]), h, wl[l + 1], dt, dev)
@@ -541,12 +583,12 @@ class HipUNet(ParameterTree):
                                                           wl[l + 1], dt, hip.stream_ptr()))
             cur = gx
             if segment_hook:
-                segment_hook(f"decoders.{i}")
+                self._segment_done(segment_hook, f"decoders.{i}")
         pre = "bottleneck.double_conv"
         g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[depth]), True)
         gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[depth]), True)
         if segment_hook:
-            segment_hook("bottleneck")
+            self._segment_done(segment_hook, "bottleneck")
         for l in reversed(range(depth)):
             pre = f"encoders.{l}.conv.double_conv"
             skip = S["cat"][l].ref(c[l], self._pp(c[l]))
@@ -556,7 +598,9 @@ class HipUNet(ParameterTree):
             g1 = self._unit_backward(units[pre + ".3"], g2.ref(c[l]), True)
             gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), l > 0)
             if segment_hook:
-                segment_hook(f"encoders.{l}")
+                self._segment_done(segment_hook, f"encoders.{l}")
+        if self._side() is not None:
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream)     # Adam (and the caller) see complete gradients
         self._saved = None
 
 
