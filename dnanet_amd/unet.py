@@ -469,6 +469,11 @@ class HipUNet(ParameterTree):
         if not self.overlap_wgrad or self.profile is not None or (torch.cuda.is_current_stream_capturing() and
                                                                    os.environ.get("DN_TUNE_NO_GRAPH_FORK")):
             return None
+        # measured (bf16, 6 x 4096): two streams win 3 % at 256 profiles, 5 % at 512, lose nothing at 768 -- and lose 40 % at
+        # 1024, where the concurrent kernels' working sets (84 GiB live) evict each other
+        S = self._saved
+        if S is not None and S["n"] * S["h"] * S["w"] > 20_000_000:
+            return None
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         return self._wgrad_stream
