@@ -12,7 +12,7 @@
 #include "ops.h"
 
 template <typename T, int KH, int KW, int HT, int EPI>
-__global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wf,
+__global__ __launch_bounds__(256, HT <= 3 ? 4 : 2) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wf,
                                                               const ConvParams p) {
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2, KS = (TAPS + 1) / 2, COT = 32;
   constexpr int EPR = RecTraits<T>::EPR, NPL = COT / EPR;
@@ -23,20 +23,9 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  const int ptile = blockIdx.x, cot = blockIdx.y;
-  int pt = ptile;
-  const int tw = pt % p.ntw; pt /= p.ntw;
-  const int th = pt % p.nth;
-  const int n = pt / p.nth;
-  const int w0 = tw * 128, h0 = th * HT;
+  const int cot = blockIdx.y;
+  const int ntiles = p.N * p.nth * p.ntw;
 
-  // input tile with its zero border
-  const float* xn = x + (long)n * p.H * p.W;
-  for (int i = tid; i < ROWS * QW; i += 256) {
-    const int r = i / QW, q = i - r * QW;
-    const int h = h0 + r - PH, w = w0 + q - PW;
-    xs[i] = (h >= 0 && h < p.H && w >= 0 && w < p.W) ? xn[(long)h * p.W + w] : 0.f;
-  }
   // this lane's taps: K step s contracts taps 2s (lower half-wave) and 2s + 1 (upper); a tap past the end has weight 0
   float a[KS];
   int boff[KS];
@@ -47,29 +36,78 @@ __global__ __launch_bounds__(256) void conv_first_mfma_kernel(const float* __res
     a[s] = tap < TAPS ? wf[tap * p.cout_pad + cot * COT + l31] : 0.f;
     boff[s] = (tc / KW) * QW + tc % KW + 32 * wave + l31;
   }
-  __syncthreads();
 
-  f32x16_t acc[HT][1];
+  // A block walks tiles blockIdx.x, + gridDim.x, ... and keeps the NEXT tile's input in flight (registers) while the matrix
+  // cores work on the current one; the epilogue's stores are fire-and-forget.  One tile per block (the first version)
+  // ran load -> MFMA -> store strictly one after the other in every co-resident block at the same time: 183 us = the sum
+  // of the three phases (44 + 86 + 51 us, scratch/first_micro.hip) for a 403 MB write.
+  constexpr int NPRE = (ROWS * QW + 255) / 256;
+  float pre[NPRE];
+  int pre_r[NPRE], pre_q[NPRE];            // a thread's elements of the tile image: the same (row, column) for every tile
 #pragma unroll
-  for (int hh = 0; hh < HT; ++hh) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[hh][0][i] = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-      acc[hh][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xs[hh * QW + boff[s]], acc[hh][0], 0, 0, 0);
+  for (int k = 0; k < NPRE; ++k) {
+    const int i = tid + k * 256;
+    pre_r[k] = i / QW - PH;
+    pre_q[k] = i % QW - PW;
   }
-
+  auto prefetch = [&](int ptile) {
+    int pt = ptile;
+    const int tw = pt % p.ntw; pt /= p.ntw;
+    const int th = pt % p.nth;
+    const int n = pt / p.nth;
+    const float* xn = x + (long)n * p.H * p.W;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int i = tid + k * 256;
+      const int h = th * HT + pre_r[k], w = tw * 128 + pre_q[k];
+#ifndef CF_ABLATE_NO_LOAD     // (ablation hooks: scratch/first_micro.hip)
+      pre[k] = (ptile < ntiles && i < ROWS * QW && h >= 0 && h < p.H && w >= 0 && w < p.W) ? xn[(long)h * p.W + w] : 0.f;
+#else
+      pre[k] = (float)(h + w);
+#endif
+    }
+  };
   float* stat_lds = (float*)(epi + 4 * NPL * 1024);
   unsigned char* pool_lds = epi + 4 * NPL * 1024 + 4 * COT * 2 * 4;
-  conv_epilogue_store<T, HT, COT, EPI>(p, acc, epi + wave * (NPL * 1024), stat_lds + wave * COT * 2,
-                                       pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
-  if constexpr (STATS) {
-    __syncthreads();
-    if (tid < COT * 2) {
-      float t = 0.f;
+
+  prefetch(blockIdx.x + p.x_plane0);     // (x_plane0: first tile of a partial launch, 0 otherwise)
+  for (int ptile = blockIdx.x + p.x_plane0; ptile < ntiles; ptile += gridDim.x) {
+    int pt = ptile;
+    const int tw = pt % p.ntw; pt /= p.ntw;
+    const int th = pt % p.nth;
+    const int n = pt / p.nth;
+    const int w0 = tw * 128, h0 = th * HT;
+    __syncthreads();                     // the previous tile's MFMAs (and its statistics sum) are done with the LDS
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) t += stat_lds[wv * COT * 2 + tid];
-      p.stats[((long)ptile * p.cout_pad + cot * COT) * 2 + tid] = t;
+    for (int k = 0; k < NPRE; ++k)
+      if (tid + k * 256 < ROWS * QW) xs[tid + k * 256] = pre[k];
+    __syncthreads();
+    prefetch(ptile + gridDim.x);
+
+    f32x16_t acc[HT][1];
+#pragma unroll
+    for (int hh = 0; hh < HT; ++hh) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[hh][0][i] = 0.f;
+#ifndef CF_ABLATE_NO_MFMA
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc[hh][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xs[hh * QW + boff[s]], acc[hh][0], 0, 0, 0);
+#else
+      acc[hh][0][0] = a[hh % KS] + xs[hh * QW + boff[0]];
+#endif
+    }
+
+    conv_epilogue_store<T, HT, COT, EPI>(p, acc, epi + wave * (NPL * 1024), stat_lds + wave * COT * 2,
+                                         pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
+    if constexpr (STATS) {
+      __syncthreads();
+      if (tid < COT * 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) t += stat_lds[wv * COT * 2 + tid];
+        p.stats[((long)ptile * p.cout_pad + cot * COT) * 2 + tid] = t;
+      }
     }
   }
 }
@@ -80,14 +118,15 @@ static int launch_ht(const float* x, const float* wf, ConvParams p, hipStream_t 
   p.nth = (p.H + HT - 1) / HT;
   const long tiles = (long)p.N * p.ntw * p.nth;
   if (tiles > 0x7fffffffL || p.cout_pad / 32 > 65535) return dn_set_error(DN_ERR_ARG, "conv_first: grid out of range");
-  const dim3 grid((unsigned)tiles, (unsigned)(p.cout_pad / 32));
+  // persistent blocks: four per CU (256 CUs), each walking every (grid)th tile
+  const dim3 grid((unsigned)std::min<long>(tiles, 1024), (unsigned)(p.cout_pad / 32));
   if (p.stats) hipLaunchKernelGGL((conv_first_mfma_kernel<T, KH, KW, HT, CONV_EPI_STATS>), grid, dim3(256), 0, s, x, wf, p);
   else hipLaunchKernelGGL((conv_first_mfma_kernel<T, KH, KW, HT, CONV_EPI_PLAIN>), grid, dim3(256), 0, s, x, wf, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }
 
-int conv_first_row_tile(int H) { return H % 5 == 0 ? 5 : H % 6 == 0 ? 6 : H % 3 == 0 ? 3 : 1; }
+int conv_first_row_tile(int H) { return H % 5 == 0 ? 5 : H % 3 == 0 ? 3 : 1; }   // 6-row tiles: 96 AGPR + 102 VGPR = 2 waves per SIMD, half the blocks in flight
 
 template <typename T, int KH, int KW>
 static int launch_k(const float* x, const float* wf, const ConvParams& p, hipStream_t s) {

@@ -134,6 +134,8 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
   unsigned char* yb = (unsigned char*)p.y;
   const int yrow = p.W * p.y_wmul;
   const bool col_ok = wbase + l31 < p.W;
+  // ReLU as ONE v_max per value against a per-launch floor (0 or -inf) instead of a max and a select on p.relu
+  const float floor_v = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     float ssum[STATS_INLOOP ? 16 : 1] = {}, ssq[STATS_INLOOP ? 16 : 1] = {};
@@ -156,8 +158,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              v[i] = acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i];
-              if (p.relu) v[i] = fmaxf(v[i], 0.f);
+              v[i] = fmaxf(acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i], floor_v);
             }
             unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
             if constexpr (sizeof(T) == 4) {
@@ -272,8 +273,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
             if (h0 + hh < p.H) {                      // block-uniform
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                float v = acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i];
-                if (p.relu) v = fmaxf(v, 0.f);
+                float v = fmaxf(acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i], floor_v);
                 if constexpr (sizeof(T) == 2) v = (float)(__bf16)v;     // statistics of the values as stored
                 v = col_ok ? v : 0.f;
                 s4[i] += v;
