@@ -12,7 +12,7 @@
 #include "ops.h"
 
 template <typename T, int KH, int KW, int HT, int EPI>
-__global__ __launch_bounds__(256, HT <= 3 ? 4 : 2) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wf,
+__global__ __launch_bounds__(256, HT > 3 ? 2 : EPI == CONV_EPI_PLAIN ? 4 : 3) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wf,
                                                               const ConvParams p) {
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2, KS = (TAPS + 1) / 2, COT = 32;
   constexpr int EPR = RecTraits<T>::EPR, NPL = COT / EPR;

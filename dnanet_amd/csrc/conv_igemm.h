@@ -247,43 +247,81 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
       }
     }
     if constexpr (STATS) {
-      // Sum over the 32 pixel lanes of each half-wave: DPP adds inside each row of 16 lanes, one exchange between the
-      // two rows of the half; lane 0 / 32 keeps the totals.
-      auto publish = [&](int cgi, int r, float a, float b) {
-        a = dn_row16_sum(a); b = dn_row16_sum(b);
-        a += __shfl_xor(a, 16);
-        b += __shfl_xor(b, 16);
-        if (l31 == 0) {
-          const int ch = cgi * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-          stat_wave[ch * 2] = a;
-          stat_wave[ch * 2 + 1] = b;
+      // Sum over the 32 pixel lanes of each half-wave, four channels (a lane's accumulator group g) at a time: the eight
+      // values [s0..s3, q0..q3] go through a butterfly that halves the number of live values per step -- lane bit 0
+      // decides who keeps the sums and who the squares, bit 1 who keeps channels 0,1 and who 2,3 (DPP quad permutes) --
+      // then the two survivors are summed over the row (row_ror 4 / 8) and over the two rows of the half.  26 VALU
+      // instructions per group instead of 48 (one full 5-step reduction per value); lanes 0..3 of each half publish.
+      auto dpp_add = [](float keep, float give, auto ctrl) {
+        return keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), decltype(ctrl)::value, 0xF, 0xF, true));
+      };
+      using QP1 = std::integral_constant<int, 0xB1>;     // quad_perm [1,0,3,2]
+      using QP2 = std::integral_constant<int, 0x4E>;     // quad_perm [2,3,0,1]
+      using ROR4 = std::integral_constant<int, 0x124>;
+      using ROR8 = std::integral_constant<int, 0x128>;
+      const bool b0 = lane & 1, b1 = lane & 2;
+      auto publish4 = [&](int cgi, int g, const float (&s4)[4], const float (&q4)[4]) {
+        float A[4], B[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A[j] = dpp_add(b0 ? q4[j] : s4[j], b0 ? s4[j] : q4[j], QP1{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          B[j] = dpp_add(b1 ? A[2 + j] : A[j], b1 ? A[j] : A[2 + j], QP2{});
+          B[j] = dpp_add(B[j], B[j], ROR4{});
+          B[j] = dpp_add(B[j], B[j], ROR8{});
+          B[j] += __shfl_xor(B[j], 16);
+        }
+        if (l31 < 4) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int ch = cgi * 32 + 8 * g + 4 * half + (b1 ? 2 : 0) + j;
+            stat_wave[ch * 2 + (b0 ? 1 : 0)] = B[j];
+          }
         }
       };
       if constexpr (STATS_INLOOP) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) publish(ps, r, ssum[r], ssq[r]);
-      } else {
-#pragma unroll
-       for (int c = 0; c < CPP; ++c)
-#pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int hh = 0; hh < HT; ++hh) {
-            if (h0 + hh < p.H) {                      // block-uniform
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                float v = fmaxf(acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i], floor_v);
-                if constexpr (sizeof(T) == 2) v = (float)(__bf16)v;     // statistics of the values as stored
-                v = col_ok ? v : 0.f;
-                s4[i] += v;
-                q4[i] = fmaf(v, v, q4[i]);
-              }
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) publish(ps * CPP + c, 4 * g + i, s4[i], q4[i]);
+          const float s4[4] = {ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]};
+          const float q4[4] = {ssq[4 * g], ssq[4 * g + 1], ssq[4 * g + 2], ssq[4 * g + 3]};
+          publish4(ps, g, s4, q4);
         }
+      } else {
+        // second walk over the accumulators, two values per instruction where the ISA has packed fp32 math
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        const bool all_cols = wbase + 31 < p.W;     // wave-uniform: no column of this wave hangs over the image edge
+        auto walk = [&](auto masked_c) {
+          constexpr bool MASKED = decltype(masked_c)::value;
+#pragma unroll
+          for (int c = 0; c < CPP; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x2_t s2[2] = {{0.f, 0.f}, {0.f, 0.f}}, q2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+              for (int hh = 0; hh < HT; ++hh) {
+                if (h0 + hh < p.H) {                      // block-uniform
+#pragma unroll
+                  for (int k = 0; k < 2; ++k) {
+                    const int r = 4 * g + 2 * k;
+                    f32x2_t v = {acc[hh][ps * CPP + c][r], acc[hh][ps * CPP + c][r + 1]};
+                    v += (f32x2_t){bias_r[c][r], bias_r[c][r + 1]};
+                    v = (f32x2_t){fmaxf(v.x, floor_v), fmaxf(v.y, floor_v)};
+                    if constexpr (sizeof(T) == 2) {       // statistics of the values as stored
+                      const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                      v = (f32x2_t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+                    }
+                    if constexpr (MASKED) v = col_ok ? v : (f32x2_t){0.f, 0.f};
+                    s2[k] += v;
+                    q2[k] = __builtin_elementwise_fma(v, v, q2[k]);
+                  }
+                }
+              }
+              const float s4[4] = {s2[0].x, s2[0].y, s2[1].x, s2[1].y}, q4[4] = {q2[0].x, q2[0].y, q2[1].x, q2[1].y};
+              publish4(ps * CPP + c, g, s4, q4);
+            }
+        };
+        if (all_cols) walk(std::false_type{}); else walk(std::true_type{});
       }
     }
   }
