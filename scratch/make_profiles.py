@@ -50,3 +50,25 @@ json.dump(rec, open(os.path.join(P, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
 print("inference:", infer_line["value"], "profiles/s; roofline", infer_line["roofline"])
 print("train_step:", full_line.get("train_step"))
+
+# matrix-core utilisation per kernel ("conv-layer MFMA utilisation from rocprof")
+mf = os.path.join(G, "pmc_mfma", "p_counter_collection.csv")
+if os.path.isfile(mf):
+    acc = defaultdict(lambda: defaultdict(float)); launches = defaultdict(int)
+    for r in csv.DictReader(open(mf)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_BUSY_CU_CYCLES":
+            launches[r["Kernel_Name"]] += 1
+    rows = sorted(acc, key=lambda k: -acc[k]["SQ_BUSY_CU_CYCLES"])[:30]
+    with open(os.path.join(P, f"{tag}_mfma_utilisation_per_kernel.csv"), "w") as f:
+        f.write("kernel,launches,mfma_busy_share_of_cu_busy_x4_simd,mfma_insts_per_launch,valu_insts_per_mfma,lds_insts_per_mfma,wave_wait_share\n")
+        for k in rows:
+            c = acc[k]
+            if c["SQ_BUSY_CU_CYCLES"] <= 0:
+                continue
+            util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+            m = c["SQ_INSTS_MFMA"]
+            per = (lambda v: f"{v / m:.2f}") if m > 0 else (lambda v: "")
+            f.write(f'"{k}",{launches[k]},{util:.3f},{m / max(launches[k], 1):.0f},{per(c["SQ_INSTS_VALU"])},'
+                    f'{per(c["SQ_INSTS_LDS"])},{c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0):.2f}\n')
+    print(open(os.path.join(P, f"{tag}_mfma_utilisation_per_kernel.csv")).read()[:3000])

@@ -12,3 +12,5 @@ timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o p -
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 $B > $R/gpurun_out/pmc_write.log 2>&1
 grep -h '"metric"' $R/gpurun_out/prof_infer_bench.log | tail -1
 grep -h '"metric"' $R/gpurun_out/prof_full_bench.log | tail -1
+# matrix-core utilisation per kernel: MFMA-busy cycles (summed over SIMDs) / (CU-busy cycles x 4 SIMDs)
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $R/gpurun_out/pmc_mfma -o p --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 $B > $R/gpurun_out/pmc_mfma.log 2>&1
