@@ -100,6 +100,7 @@ __device__ __forceinline__ double wave_sum_partials(const float* partial, int nb
 // RED_SEG pieces and the (image, segment) units are dealt round-robin to the blocks of a plane.  A thread reads four
 // pieces 256 apart per step (independent loads in flight: a single dependent load per thread left HBM at ~4 TB/s);
 // its piece parity, hence its channels, is fixed (threadIdx.x & 1).
+constexpr int BWD_ILP = 4;         // bn_bwd_reduce_kernel: loads of g and of y in flight per thread (2 left HBM at 4.9 TB/s)
 constexpr int RED_SEG = 4096;      // pieces per unit at large batch; red_seg() shrinks it when there are few images
 
 template <typename T>
@@ -287,17 +288,17 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsign
     const unsigned char* gbase = g + ((long)n * g_pt + g_p0 + plane) * npieces * 16;
     const unsigned char* ybase = y + ((long)n * y_pt + y_p0 + plane) * npieces * 16;
     const int iend = min(npieces, (seg + 1) * seg_len);
-    for (int i = seg * seg_len + threadIdx.x; i < iend; i += 2 * RED_THREADS) {
-      uint4 vg[2], vy[2];
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += BWD_ILP * RED_THREADS) {
+      uint4 vg[BWD_ILP], vy[BWD_ILP];             // BWD_ILP pieces of g and of y in flight per thread
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < BWD_ILP; ++k) {
         const int ii = i + k * RED_THREADS;
         const bool in = ii < iend;
         vg[k] = in ? *(const uint4*)(gbase + (long)ii * 16) : make_uint4(0, 0, 0, 0);   // g = 0 adds nothing
         vy[k] = in ? *(const uint4*)(ybase + (long)ii * 16) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < BWD_ILP; ++k) {
         float fg[PN], fy[PN];
         Piece<T>::unpack(vg[k], fg);
         Piece<T>::unpack(vy[k], fy);
@@ -448,24 +449,39 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 }
 
 // per-channel sum over pixels of x * (scale ? scale[pixel] : 1):  head weight gradient (scale = dlogit),
-// ConvTranspose bias gradient (scale = null)
+// ConvTranspose bias gradient (scale = null).  Work split as bn_stats_kernel: (image, segment) units of a plane's contiguous
+// 16-byte pieces dealt round-robin to the blocks, four pieces in flight per thread, no division in the loop (the first
+// version walked pixels with a wrap-around loop that spun 40 times per step on the 256-column planes: 2.6 TB/s).
 template <typename T>
-__global__ __launch_bounds__(RED_THREADS) void channel_sum_kernel(const unsigned char* x, int x_pt, int x_p0, long N, long HW,
-                                                                   const float* __restrict__ pixscale, float* partial, int cpad) {
+__global__ __launch_bounds__(RED_THREADS) void channel_sum_kernel(const unsigned char* x, int x_pt, int x_p0, int N, int npieces,
+                                                                   int seg_len, const float* __restrict__ pixscale, float* partial,
+                                                                   int cpad) {
   constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
-  const int plane = blockIdx.y, pc = threadIdx.x & 1;
+  const int plane = blockIdx.y;
   float acc[1][PN] = {};
-  const long total = N * HW;
-  const long step = (long)gridDim.x * 128;
-  long i = (long)blockIdx.x * 128 + (threadIdx.x >> 1);
-  long n = i / HW, hw = i - n * HW;          // one division per thread; then carried along
-  for (; i < total; i += step, hw += step) {
-    while (hw >= HW) { hw -= HW; ++n; }
-    float f[PN];
-    Piece<T>::unpack(*(const uint4*)(x + rec_off(x_pt, x_p0 + plane, n, hw, HW) + 16 * pc), f);
-    const float s = pixscale ? pixscale[i] : 1.f;
+  const int nseg = (npieces + seg_len - 1) / seg_len;
+  for (int u = blockIdx.x; u < N * nseg; u += gridDim.x) {
+    const int n = u / nseg, seg = u - n * nseg;
+    const unsigned char* base = x + ((long)n * x_pt + x_p0 + plane) * npieces * 16;
+    const float* ps = pixscale ? pixscale + (long)n * (npieces >> 1) : nullptr;
+    const int iend = min(npieces, (seg + 1) * seg_len);
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += 4 * RED_THREADS) {
+      uint4 v[4];
+      float sc[4];
 #pragma unroll
-    for (int j = 0; j < PN; ++j) acc[0][j] = fmaf(f[j], s, acc[0][j]);
+      for (int k = 0; k < 4; ++k) {
+        const int ii = i + k * RED_THREADS;
+        v[k] = ii < iend ? *(const uint4*)(base + (long)ii * 16) : make_uint4(0, 0, 0, 0);
+        sc[k] = (ps && ii < iend) ? ps[ii >> 1] : 1.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f[PN];
+        Piece<T>::unpack(v[k], f);
+#pragma unroll
+        for (int j = 0; j < PN; ++j) acc[0][j] = fmaf(f[j], sc[k], acc[0][j]);
+      }
+    }
   }
   block_reduce_store<1, PN>(acc, partial, cpad, plane, EPR);
 }
@@ -845,6 +861,7 @@ int dn_head_1x1_backward(const float* dlogits, dn_tensor x, const float* w, dn_t
                          int N, int H, int W, int dtype, void* stream) {
   DN_CHECK_ARG(dlogits && x.base && w && g.base && dw && db && partial, "dn_head_1x1_backward: null pointer");
   DN_CHECK_ARG(x.channels == g.channels, "dn_head_1x1_backward: channel mismatch");
+  DN_CHECK_ARG(N > 0 && (long)H * W > 0 && (long)H * W * 2 < (1L << 31), "dn_head_1x1_backward: bad shape / plane too large");
   const int C = x.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
   hipStream_t s = (hipStream_t)stream;
@@ -856,8 +873,8 @@ int dn_head_1x1_backward(const float* dlogits, dn_tensor x, const float* w, dn_t
   DN_LAUNCH_CHECK();
   const int nblk = red_blocks((long)N * HW);
   DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(channel_sum_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, (long)N, HW, dlogits, partial, cpad),
-    hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, (long)N, HW, dlogits, partial, cpad),
+    hipLaunchKernelGGL(channel_sum_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), dlogits, partial, cpad),
+    hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), dlogits, partial, cpad),
     "dn_head_1x1_backward");
   DN_LAUNCH_CHECK();
   hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(64), 0, s, partial, nblk, cpad, C, dw);
@@ -876,11 +893,12 @@ int dn_channel_sum(dn_tensor x, float* out, float* partial, int N, int H, int W,
   DN_CHECK_ARG(x.base && out && partial, "dn_channel_sum: null pointer");
   const int C = x.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
+  DN_CHECK_ARG(N > 0 && HW > 0 && HW * 2 < (1L << 31) && nplanes < 65536, "dn_channel_sum: bad shape / plane too large for the launch grid");
   const int nblk = red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
   DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(channel_sum_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, (long)N, HW, (const float*)nullptr, partial, cpad),
-    hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, (long)N, HW, (const float*)nullptr, partial, cpad),
+    hipLaunchKernelGGL(channel_sum_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), (const float*)nullptr, partial, cpad),
+    hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), (const float*)nullptr, partial, cpad),
     "dn_channel_sum");
   DN_LAUNCH_CHECK();
   hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(C), dim3(64), 0, s, partial, nblk, cpad, C, out);
