@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline leg only (no fp32 / 5-dye legs, no parity counts)")
     ap.add_argument("--global-batch", type=int, default=2048, help="configs[3]: global batch of the strong-scaling train leg (N > 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1: nccl = RCCL over xGMI (the measured configuration); gloo lets the whole "
+                         "N > 1 path be rehearsed with several ranks sharing one GPU (collectives staged through the host)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous rehearsal on the CPU (gloo, stub step, no GPU): what the tests use")
     return ap.parse_args(argv)
@@ -270,7 +273,8 @@ def train_leg(dtype, rows, batch, steps, dev, rank, world, distributed, barrier,
     out = {"value": round(pps, 1), "unit": "profiles/s", "dtype": "bf16" if dtype == "bf16" else "f32", "steps": steps,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "per_gpu_batch": batch, "global_batch": batch * world,
            "rows": rows, "loss": round(loss, 5),
-           "parallelism": f"dp{world}" + (" (RCCL sum-all-reduce of Dice sums + bucketed gradient arena)" if world > 1 else ""),
+           "parallelism": f"dp{world}" + (f" ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} sum-all-reduce of Dice sums "
+                                          "+ bucketed gradient arena)" if distributed else ""),
            "whole_step_mfma_frac": round(pps / world * TRAIN_FLOP_H5 * rows / 5 / 1e12 / peak_of(dtype), 4)}
     if comm:
         out["comm"] = comm
@@ -349,11 +353,18 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        print(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible); RCCL needs one device per rank", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local_rank % max(ndev, 1))        # gloo rehearsal: ranks may share a device
+    torch.cuda.set_device(dev)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     def barrier():
         if distributed:
@@ -363,7 +374,7 @@ def main():
     def reduce_max(seconds):
         if not distributed:
             return seconds
-        tmax = torch.tensor([seconds], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([seconds], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax)
 
@@ -378,7 +389,7 @@ def main():
         "config": {"workload": f"U-Net depth4 k(3,5) f32 eval forward, batch {args.batch}/GPU, {args.rows} dyes x 4096 scans "
                                f"(BASELINE.json configs[1], {args.dtype} half)", "global_batch": args.batch * world,
                    "parallelism": f"replicas x{world} (inference shards by profile, no collective)",
-                   "world_size_seen_by_rank0": world},
+                   "world_size_seen_by_rank0": world, **({"backend": args.backend, "devices": ndev} if distributed else {})},
         "roofline": roofline,
     }
     if not args.no_legs and not distributed:
