@@ -121,9 +121,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   // constant, which lets the products with a zero halo row be left out below -- and accumulator 3 is column 4 of kernel
   // row w (waves 0..2; wave 3 has none).
   static_assert(KSPLIT || (KH == 3 && KW == 5 && WT == 4), "tap-to-wave map is written for 3x5");
-  const bool rowmap = p.skip_halo != 2;     // (tuning: 2 = the interleaved map tap = wave + 4 i)
   auto tap_of = [&](int i) {
-    return KSPLIT ? i : !rowmap ? min(wave + 4 * i, TAPS - 1) : (i < KH ? i * KW + wave : min(wave, KH - 1) * KW + KW - 1);
+    return KSPLIT ? i : (i < KH ? i * KW + wave : min(wave, KH - 1) * KW + KW - 1);
   };
   int tap_off[WT];
 #pragma unroll
@@ -247,7 +246,70 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     (void)smem;
 #ifndef WG_ABLATE_NO_COMPUTE
     // ---- MFMA over the strip's pixels
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && !KSPLIT) {
+      // Fragment reads are what bounds this kernel (ds_read_b64_tr_b16: 1.5 per MFMA when every (tap, strip row) fetches
+      // its own A fragment).  Accumulator i < KH of a wave is tap (kernel row i, column = wave): at strip row r it multiplies
+      // A row r + i, so A row rho of one K step serves (i, r) = (0, rho), (1, rho - 1), (2, rho - 2).  The strip rows are
+      // therefore the INNER loop and the wave keeps a sliding window of KH A-row fragments: HT + KH - 1 row fragments per
+      // K step instead of KH * HT (3 rows: 28 instead of 36 reads per 24 MFMAs, 5 rows: 44 instead of 60 per 40).
+      // Everything is unrolled: g[][] are plain registers whose live ranges the compiler sees.
+      static_assert(NCIG == 1 && WT == KH + 1, "window scheme: one input-channel group, KH row taps + one extra per wave");
+      constexpr int NIT = HT * NK;
+      const unsigned char* dbase0 = smem + frag_off;
+      const unsigned char* abase0 = smem + frag_off + DY_BYTES + (A_PS - DY_PS) * gpl_c;
+      auto rd = [&](const unsigned char* base) {
+#ifdef WG_ABLATE_NO_FRAG          // (ablation hook, scratch/wgrad_micro.hip: no fragment reads)
+        const unsigned v = (unsigned)(size_t)base;
+        return make_uint4(v, v, v, v);
+#else
+        const uint2 lo = lds_tr16_b64(base), hi = lds_tr16_b64(base + 4 * 32);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+#endif
+      };
+      uint4 af[2][NCOG], bx[2], g[NK][HT + KH - 1];
+      auto load_step = [&](int s) {
+        const int ks = s / HT, r = s - ks * HT;
+#pragma unroll
+        for (int cg = 0; cg < NCOG; ++cg) af[s & 1][cg] = rd(dbase0 + cg * PLG * DY_PS + (r * SW + ks * 16) * 32);
+        bx[s & 1] = rd(abase0 + tap_off[KH] + (r * QW + ks * 16) * 32);
+#pragma unroll
+        for (int rho = 0; rho < HT + KH - 1; ++rho) {
+          if (rho > r + KH - 1 || (r > 0 && rho < r + KH - 1)) continue;        // new rows of the window only
+          if ((TOP && rho == 0) || (BOT && rho == HT + KH - 2)) continue;       // zero halo row: nobody multiplies it
+          g[ks][rho] = rd(abase0 + tap_off[0] + (rho * QW + ks * 16) * 32);
+        }
+      };
+      constexpr int PPI = (ST_ITERS + NIT - 1) / NIT;   // pieces of the next strip staged per K step
+      load_step(0);
+#ifndef WG_ABLATE_NO_STAGE
+      const StageCtx sc = stage_begin_checked(nxt_strip, nxt_buf);
+#endif
+#pragma unroll
+      for (int s = 0; s < NIT; ++s) {
+        if (s + 1 < NIT) load_step(s + 1);
+#ifndef WG_ABLATE_NO_STAGE
+#pragma unroll
+        for (int k = s * PPI; k < (s + 1) * PPI && k < ST_ITERS; ++k) stage_piece(sc, k);
+#endif
+        const int ks = s / HT, r = s - ks * HT;
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+          if (dead(i, r)) continue;
+#pragma unroll
+          for (int a = 0; a < NCOG; ++a)
+            acc[i][a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s & 1][a]),
+                                                                   __builtin_bit_cast(bf16x8_t, g[ks][r + i]), acc[i][a][0], 0, 0, 0);
+        }
+        // the extra tap (column KW-1 of kernel row `wave`); the wave without one reads its fragments (no branch in the
+        // read stream) but skips the MFMAs, which are what the power budget pays for
+        if (last_tap_real) {
+#pragma unroll
+          for (int a = 0; a < NCOG; ++a)
+            acc[KH][a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s & 1][a]),
+                                                                    __builtin_bit_cast(bf16x8_t, bx[s & 1]), acc[KH][a][0], 0, 0, 0);
+        }
+      }
+    } else if constexpr (sizeof(T) == 2) {
       // register double buffering: the fragments of K step it+1 are read while the MFMAs of step it run
       constexpr int NIT = KSPLIT ? NK / 4 : HT * NK;
       auto load_frags = [&](int it, uint4 (&af)[NCOG], uint4 (&bf)[WT][NCIG]) {
@@ -401,7 +463,7 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   if (nsplit % 8) xcd = false;
   if (nsplit < 1) return dn_set_error(DN_ERR_ARG, "conv_wgrad: workspace of %ld bytes is smaller than one partial slab (%ld)",
                                       slab_bytes, per_slab);
-  p.skip_halo = dn_tune().wgrad_noskip == 2 ? 2 : dn_tune().wgrad_noskip == 1 ? 0 : 1;
+  p.skip_halo = dn_tune().wgrad_noskip ? 0 : 1;
   p.nsplit = (int)nsplit;
   p.xcd_split = xcd ? 1 : 0;
   *nslab_out = (int)nsplit * (KSPLIT ? 4 : 1);
