@@ -37,6 +37,7 @@ static ConvVariant choose_variant(const ConvParams& p, int kh, int kw, int dtype
   v.wave8 = !tune.no_conv8 && v.cot == 64 && conv_igemm8_applies(p, kh, kw) &&
             (dtype == DN_F32 || (dtype == DN_BF16 && (v.ht == 5 || tune.conv8_ht3)));
   if (p.head_w) v.wave8 = false;     // the fused head lives in the 4-wave kernel's epilogue
+  if (p.y_lo_off && v.ht != 5) v.wave8 = false;   // split epilogue: the 8-wave kernel is built for 5-row tiles only
   if (p.stats && tune.stats_4wave) v.wave8 = false;
   // Small batches (train.py's 16 profiles): the wide tiles leave CUs idle -- every 8-wave launch of the shipped net
   // is exactly 128 workgroups at N = 16.  Step down to the tile that still gives two workgroups per CU.
@@ -54,6 +55,13 @@ static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t
   if (dtype != DN_BF16 && dtype != DN_F32) return dn_set_error(DN_ERR_ARG, "bad dtype %d", dtype);
   const ConvVariant v = choose_variant(p, kh, kw, dtype);
   const int ht = v.ht, cot = v.cot;
+  if (p.y_lo_off) {                  // hi + lo split output (bf16x3 inference mode)
+    if (dtype != DN_BF16) return dn_set_error(DN_ERR_ARG, "split output needs bf16 storage");
+    if (v.wave8) return conv_igemm8_run_bf16_split(p, ht, s);
+    if (kh == 3 && kw == 5) return conv_igemm_run_bf16_k35_split(p, ht, cot, s);
+    if (kh == 1 && kw == 1) return conv_igemm_run_bf16_k11_split(p, ht, cot, s);
+    return dn_set_error(DN_ERR_UNSUPPORTED, "split output: kernel size (%d,%d) is not built (have (3,5), (1,1))", kh, kw);
+  }
   if (v.wave8) return dtype == DN_BF16 ? conv_igemm8_run_bf16(p, ht, s) : conv_igemm8_run_f32(p, ht, s);
   if (dtype == DN_BF16) {
     if (kh == 3 && kw == 5) return conv_igemm_run_bf16_k35(p, ht, cot, s);
@@ -78,7 +86,7 @@ static void flatten_rows(ConvParams& p) {
 extern "C" {
 
 const char* dn_last_error(void) { return g_err; }
-int dn_abi_version(void) { return 2; }
+int dn_abi_version(void) { return 3; }
 
 int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len) {
   DN_CHECK_ARG(buf && buf_len > 0, "dn_conv2d_variant: no buffer");
@@ -185,12 +193,84 @@ int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx
   DN_CHECK_ARG(dy.plane0 + yp <= dy.planes_total && dx.plane0 + xp <= dx.planes_total, "dn_conv_transpose_1x2_dgrad: planes outside buffer");
   const int gsize = dn_channel_pad(dy.channels);
   ConvParams p{};
-  p.x = dy.base; p.x_planes_total = dy.planes_total; p.x_plane0 = dy.plane0; p.x_nplanes = yp; p.x_gplanes = gsize / epr; p.x_wmul = 2;
+  p.x = dy.base; p.x_planes_total = dy.planes_total; p.x_plane0 = dy.plane0; p.x_nplanes = yp; p.x_gplanes = gsize / epr; p.x_wmul = 2; p.x_gstride = 1;
   p.w = packed_w; p.bias = nullptr;
   p.y = dx.base; p.y_planes_total = dx.planes_total; p.y_plane0 = dx.plane0; p.y_nplanes = xp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
   p.N = N; p.H = H; p.W = Win; p.nchunk = 2 * (gsize / epr); p.cout_pad = dn_channel_pad(dx.channels); p.relu = 0;
   flatten_rows(p);
   return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);
+}
+
+// ---- bf16x3: hi + lo split activations and weights (inference).  See include/dnanet_hip.h.
+// K walk of a split input [hi | lo | hi] against the image [W_hi | W_hi | W_lo]; of a plain input [x | x] against [W_hi | W_lo].
+static int x3_input(ConvParams& p, const dn_tensor_x3& x, const char* who) {
+  const int xp = dn_planes(x.channels, DN_BF16);
+  if (!x.base || x.plane0 < 0 || x.lo_off < 0 || x.plane0 + (x.lo_off ? x.lo_off : 0) + xp > x.planes_total)
+    return dn_set_error(DN_ERR_ARG, "%s: x planes [%d,%d) (+ lo part at +%d) outside buffer of %d", who, x.plane0, x.plane0 + xp,
+                        x.lo_off, x.planes_total);
+  if (x.lo_off && x.lo_off < xp) return dn_set_error(DN_ERR_ARG, "%s: x.lo_off %d overlaps the %d hi planes", who, x.lo_off, xp);
+  p.x = x.base; p.x_planes_total = x.planes_total; p.x_plane0 = x.plane0; p.x_nplanes = xp; p.x_gplanes = xp; p.x_wmul = 1;
+  p.x_gstride = 0; p.x_lo_off = x.lo_off;
+  p.nchunk = (x.lo_off ? 3 : 2) * xp;
+  return DN_OK;
+}
+static int x3_output(ConvParams& p, const dn_tensor_x3& y, const char* who) {
+  const int yp = dn_planes(y.channels, DN_BF16);
+  if (!y.base || y.plane0 < 0 || y.lo_off < yp || y.plane0 + y.lo_off + yp > y.planes_total)
+    return dn_set_error(DN_ERR_ARG, "%s: y planes [%d,%d) + lo part at +%d outside buffer of %d (a split output needs lo_off >= its planes)",
+                        who, y.plane0, y.plane0 + yp, y.lo_off, y.planes_total);
+  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.y_lo_off = y.lo_off;
+  return DN_OK;
+}
+
+int dn_conv2d_x3(dn_tensor_x3 x, const void* packed_w, const float* bias, dn_tensor_x3 y, const dn_tensor_x3* pooled, int N, int H,
+                 int W, int kh, int kw, int relu, void* stream) {
+  DN_CHECK_ARG(packed_w, "dn_conv2d_x3: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && x.channels > 0 && y.channels > 0, "dn_conv2d_x3: bad shape N=%d H=%d W=%d", N, H, W);
+  DN_CHECK_ARG(kh == 3 && kw == 5, "dn_conv2d_x3: kernel size (%d,%d) is not built (have (3,5))", kh, kw);
+  ConvParams p{};
+  if (int rc = x3_input(p, x, "dn_conv2d_x3")) return rc;
+  if (int rc = x3_output(p, y, "dn_conv2d_x3")) return rc;
+  p.w = packed_w; p.bias = bias;
+  p.N = N; p.H = H; p.W = W; p.cout_pad = dn_channel_pad(y.channels); p.relu = relu;
+  if (pooled) {
+    const int pp = dn_planes(pooled->channels, DN_BF16);
+    DN_CHECK_ARG(pooled->base && W % 2 == 0 && pooled->channels == y.channels, "dn_conv2d_x3: pooled tensor needs W even and y's channels");
+    DN_CHECK_ARG(pooled->plane0 >= 0 && (pooled->lo_off == 0 || pooled->lo_off >= pp) &&
+                 pooled->plane0 + pooled->lo_off + pp <= pooled->planes_total, "dn_conv2d_x3: pooled planes outside buffer");
+    p.pool = pooled->base; p.pool_planes_total = pooled->planes_total; p.pool_plane0 = pooled->plane0; p.pool_lo_off = pooled->lo_off;
+  }
+  return run_igemm(p, kh, kw, DN_BF16, (hipStream_t)stream);
+}
+
+int dn_conv2d_head_x3(dn_tensor_x3 x, const void* packed_w, const float* bias, int cout, const float* head_w, const float* head_b,
+                      float* logits, float* probs, int N, int H, int W, int kh, int kw, int relu, void* stream) {
+  DN_CHECK_ARG(packed_w && head_w && head_b && (logits || probs), "dn_conv2d_head_x3: null pointer");
+  if (!head_fits(x.channels, cout, N, H, W, kh, kw, DN_BF16))
+    return dn_set_error(DN_ERR_UNSUPPORTED, "dn_conv2d_head_x3: no single-tile kernel for cout=%d at N=%d H=%d W=%d k=(%d,%d)", cout, N,
+                        H, W, kh, kw);
+  ConvParams p{};
+  if (int rc = x3_input(p, x, "dn_conv2d_head_x3")) return rc;
+  p.w = packed_w; p.bias = bias;
+  p.y = nullptr; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.N = N; p.H = H; p.W = W; p.cout_pad = dn_channel_pad(cout); p.relu = relu;
+  p.head_w = head_w; p.head_b = head_b; p.head_logits = logits; p.head_probs = probs; p.head_exact = 1;
+  return run_igemm(p, kh, kw, DN_BF16, (hipStream_t)stream);
+}
+
+int dn_conv_transpose_1x2_x3(dn_tensor_x3 x, const void* packed_w, const float* bias2, dn_tensor_x3 y, int N, int H, int Win,
+                             void* stream) {
+  DN_CHECK_ARG(packed_w, "dn_conv_transpose_1x2_x3: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && Win > 0, "dn_conv_transpose_1x2_x3: bad shape");
+  ConvParams p{};
+  if (int rc = x3_input(p, x, "dn_conv_transpose_1x2_x3")) return rc;
+  if (int rc = x3_output(p, y, "dn_conv_transpose_1x2_x3")) return rc;
+  p.w = packed_w; p.bias = bias2;
+  p.y_wmul = 2;        // GEMM plane 2j + k is output column 2w + k of plane j (the epilogue stores the pair together)
+  p.N = N; p.H = H; p.W = Win; p.cout_pad = 2 * dn_channel_pad(y.channels); p.relu = 0;
+  flatten_rows(p);
+  return run_igemm(p, 1, 1, DN_BF16, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -21,9 +21,15 @@
 
 struct ConvParams {
   const void* x; int x_planes_total, x_plane0, x_nplanes, x_gplanes, x_wmul;
+  // virtual K plane ck -> group ck / x_gplanes, plane ck % x_gplanes.  A group is shifted by x_gstride records (the
+  // transposed convolution's data gradient: group k = output column 2w + k) and odd groups by x_lo_off planes (hi + lo
+  // split activations, K walk [hi | lo | hi] against the weight image [W_hi | W_hi | W_lo]; 0 otherwise)
+  int x_gstride, x_lo_off;
   const void* w;            // packed [nchunk][TAPS][cout_pad][32 B]
   const float* bias;        // [cout_pad] (virtual channel order) or nullptr
   void* y; int y_planes_total, y_plane0, y_nplanes, y_gplanes, y_wmul;
+  int y_lo_off, pool_lo_off; // split epilogues: planes between a tensor's hi part and its lo part (pool_lo_off 0: pooled output is plain bf16)
+  int head_exact;            // head epilogue: do not round the activation to the storage type first (split mode)
   int N, H, W;              // pixel grid of the GEMM (per group)
   int nchunk;               // K chunks = virtual input planes
   int cout_pad;             // multiple of COT
@@ -60,6 +66,8 @@ constexpr int CONV_EPI_PLAIN = 0;   // nothing
 constexpr int CONV_EPI_STATS = 1;   // + BatchNorm batch statistics of y (training forward)
 constexpr int CONV_EPI_POOL = 2;    // + MaxPool2d((1,2)) of y into a second buffer (encoder blocks, eval mode)
 constexpr int CONV_EPI_HEAD = 3;    // instead of storing y: the 1x1 output convolution + sigmoid over it (last block, eval mode)
+constexpr int CONV_EPI_SPLIT = 4;   // bf16 only: y = hi + lo, two bf16 tensors p.y_lo_off planes apart (~16 mantissa bits kept)
+constexpr int CONV_EPI_POOL_SPLIT = 5;   // SPLIT + POOL (the pooled tensor split too when p.pool_lo_off > 0)
 
 // Head form of the epilogue (unet_architecture.py:94-97 + trainable_unet.py:409 fused into the last DoubleConv): the
 // block holds every channel of its pixels (cout_pad == COT), a lane 16 of them, so logit = sum_c w_c * act_c + b is a
@@ -91,7 +99,7 @@ __device__ __forceinline__ void conv_epilogue_head(const ConvParams& p, f32x16_t
         for (int r = 0; r < 16; ++r) {
           float v = acc[hh][cg][r] + bias_r[cg][r];
           if (p.relu) v = fmaxf(v, 0.f);
-          if constexpr (sizeof(T) == 2) v = (float)(__bf16)v;
+          if constexpr (sizeof(T) == 2) { if (!p.head_exact) v = (float)(__bf16)v; }
           dot = fmaf(v, hw[cg][r], dot);
         }
       dot += __shfl_xor(dot, 32);
@@ -122,7 +130,10 @@ template <typename T, int HT, int COT, int EPI, bool PAIRS = false>
 __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_t (&acc)[HT][COT / 32], unsigned char* scratch,
                                                     float* stat_wave, unsigned char* pool_scratch, int n, int h0, int wbase,
                                                     int cot, int lane) {
-  constexpr bool STATS = EPI == CONV_EPI_STATS, POOL = EPI == CONV_EPI_POOL;
+  constexpr bool STATS = EPI == CONV_EPI_STATS, POOL = EPI == CONV_EPI_POOL || EPI == CONV_EPI_POOL_SPLIT;
+  constexpr bool SPLIT = EPI == CONV_EPI_SPLIT || EPI == CONV_EPI_POOL_SPLIT;
+  static_assert(!SPLIT || sizeof(T) == 2, "hi + lo split exists for bf16 storage only");
+  constexpr int NPART = SPLIT ? 2 : 1;          // part 0 stores bf16(v), part 1 bf16(v - bf16(v)) y_lo_off planes further
   constexpr int NCG = COT / 32, EPR = RecTraits<T>::EPR, GPL = 32 / EPR;
   // where the statistics are accumulated: inside the store loop (16 + 16 live sums per lane, hence one pass per channel
   // group), or -- for the 3-row x 64-channel tile, where those 40 registers cost the third workgroup per CU (+160..240 us
@@ -151,6 +162,8 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
       const int h = h0 + hh;
       if (h < p.H) {                                  // block-uniform
 #pragma unroll
+       for (int part = 0; part < NPART; ++part) {
+#pragma unroll
         for (int c = 0; c < CPP; ++c) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -165,6 +178,10 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
               *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
             } else {
               __bf16 bq[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              if (SPLIT && part == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bq[i] = (__bf16)(v[i] - (float)bq[i]);
+              }
               uint2 u;
               u.x = (uint32_t)__builtin_bit_cast(unsigned short, bq[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[1]) << 16);
               u.y = (uint32_t)__builtin_bit_cast(unsigned short, bq[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[3]) << 16);
@@ -190,6 +207,10 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
                   *(float4*)pd = make_float4(m[0], m[1], m[2], m[3]);
                 } else {
                   __bf16 bq[4] = {(__bf16)m[0], (__bf16)m[1], (__bf16)m[2], (__bf16)m[3]};
+                  if (SPLIT && part == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bq[i] = (__bf16)(m[i] - (float)bq[i]);
+                  }
                   uint2 u;
                   u.x = (uint32_t)__builtin_bit_cast(unsigned short, bq[0]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[1]) << 16);
                   u.y = (uint32_t)__builtin_bit_cast(unsigned short, bq[2]) | ((uint32_t)__builtin_bit_cast(unsigned short, bq[3]) << 16);
@@ -209,7 +230,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
               const int px = hf * 16 + (lane >> 2), k = (lane >> 1) & 1, pc = lane & 1;
               const uint4 val = *(const uint4*)(scratch + (2 * pp + k) * 1024 + px * 32 + pc * 16);
               if (yplane < p.y_nplanes && wbase + px < p.W) {
-                const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow + (long)(wbase + px) * 2 + k;
+                const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane + part * p.y_lo_off) * p.H + h) * yrow + (long)(wbase + px) * 2 + k;
                 *(uint4*)(yb + rec * 32 + 16 * pc) = val;
               }
             }
@@ -226,7 +247,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
           if (val.x == 0x12345678u)
 #endif
           if (yplane < p.y_nplanes && wbase + px < p.W) {
-            const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane) * p.H + h) * yrow +
+            const long rec = ((long)(n * p.y_planes_total + p.y_plane0 + yplane + part * p.y_lo_off) * p.H + h) * yrow +
                              (long)(wbase + px) * p.y_wmul + ygrp;
             *(uint4*)(yb + rec * 32 + 16 * pc) = val;
           }
@@ -238,12 +259,13 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
           for (int pl = 0; pl < CPP * GPL; ++pl) {
             const int yplane = (cot * NCG + ps * CPP) * GPL + pl;
             const uint4 val = *(const uint4*)(pool_scratch + pl * 512 + (lane & 31) * 16);
-            if (lane < 32 && yplane < p.y_nplanes && (wbase >> 1) + px < wp) {
-              const long rec = ((long)(n * p.pool_planes_total + p.pool_plane0 + yplane) * p.H + h) * wp + (wbase >> 1) + px;
+            if (lane < 32 && yplane < p.y_nplanes && (wbase >> 1) + px < wp && (part == 0 || p.pool_lo_off > 0)) {
+              const long rec = ((long)(n * p.pool_planes_total + p.pool_plane0 + yplane + part * p.pool_lo_off) * p.H + h) * wp + (wbase >> 1) + px;
               *(uint4*)((unsigned char*)p.pool + rec * 32 + 16 * pc) = val;
             }
           }
         }
+       }
       }
     }
     if constexpr (STATS) {
@@ -429,8 +451,8 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
     const int grp = ck / p.x_gplanes;
     const int plane = ck - grp * p.x_gplanes;
     const bool exists = ck < p.nchunk && plane < p.x_nplanes;
-    const long plane_base = ((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow;
-    dn_srd_t srd_x = dn_make_srd(xb + (exists ? plane_base * 32 + (long)grp * 32 : 0));
+    const long plane_base = ((long)(n * p.x_planes_total + p.x_plane0 + plane + ((grp & 1) ? p.x_lo_off : 0)) * p.H) * xrow;
+    dn_srd_t srd_x = dn_make_srd(xb + (exists ? plane_base * 32 + (long)grp * p.x_gstride * 32 : 0));
     dn_srd_t srd_w = dn_make_srd(wb + (exists ? ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32 : 0));
     if (!exists) { srd_x.z = 0; srd_w.z = 0; }
 #ifndef CV_ABLATE_NO_STAGE   // (ablation hooks: scratch/conv_micro.hip)

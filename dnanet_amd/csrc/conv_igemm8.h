@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   auto srd_act = [&](int ck) {
     const int grp = ck / p.x_gplanes, plane = ck - grp * p.x_gplanes;
     const bool ex = chunk_exists(ck);
-    dn_srd_t s = dn_make_srd(xb + (ex ? (((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow + grp) * 32 : 0));
+    dn_srd_t s = dn_make_srd(xb + (ex ? (((long)(n * p.x_planes_total + p.x_plane0 + plane + ((grp & 1) ? p.x_lo_off : 0)) * p.H) * xrow + (long)grp * p.x_gstride) * 32 : 0));
     if (!ex) s.z = 0;
     return s;
   };
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p
     const int grp = ck / p.x_gplanes;
     const int plane = ck - grp * p.x_gplanes;
     const bool exists = ck < p.nchunk && plane < p.x_nplanes;
-    dn_srd_t srd_x = dn_make_srd(xb + (exists ? (((long)(n * p.x_planes_total + p.x_plane0 + plane) * p.H) * xrow + grp) * 32 : 0));
+    dn_srd_t srd_x = dn_make_srd(xb + (exists ? (((long)(n * p.x_planes_total + p.x_plane0 + plane + ((grp & 1) ? p.x_lo_off : 0)) * p.H) * xrow + (long)grp * p.x_gstride) * 32 : 0));
     dn_srd_t srd_w = dn_make_srd(wb + (exists ? ((long)ck * TAPS * p.cout_pad + (long)cot * COT) * 32 : 0));
     if (!exists) { srd_x.z = 0; srd_w.z = 0; }
 #pragma unroll

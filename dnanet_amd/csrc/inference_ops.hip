@@ -267,6 +267,22 @@ int dn_conv_first(const float* x, const float* wf, const float* bias, dn_tensor 
   return dn_set_error(DN_ERR_ARG, "dn_conv_first: bad dtype %d", dtype);
 }
 
+int dn_conv_first_x3(const float* x, const float* wf, const float* bias, dn_tensor_x3 y, int N, int H, int W, int cout, int kh,
+                     int kw, int relu, void* stream) {
+  DN_CHECK_ARG(x && wf && y.base, "dn_conv_first_x3: null pointer");
+  DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && cout > 0 && y.channels == cout, "dn_conv_first_x3: bad shape N=%d H=%d W=%d cout=%d", N, H, W, cout);
+  DN_CHECK_ARG(kh == 3 && kw == 5, "dn_conv_first_x3: kernel size (%d,%d) is not built (have (3,5))", kh, kw);
+  const int yp = dn_planes(cout, DN_BF16);
+  DN_CHECK_ARG(y.plane0 >= 0 && y.lo_off >= yp && y.plane0 + y.lo_off + yp <= y.planes_total,
+               "dn_conv_first_x3: y planes [%d,%d) + lo part at +%d outside buffer of %d", y.plane0, y.plane0 + yp, y.lo_off, y.planes_total);
+  ConvParams p{};
+  p.bias = bias;
+  p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
+  p.y_lo_off = y.lo_off;
+  p.N = N; p.H = H; p.W = W; p.cout_pad = dn_channel_pad(cout); p.relu = relu;
+  return conv_first_mfma_run(x, wf, p, kh, kw, DN_BF16, (hipStream_t)stream);
+}
+
 int dn_maxpool_1x2(dn_tensor x, dn_tensor y, int N, int H, int Wout, int dtype, void* stream) {
   DN_CHECK_ARG(x.base && y.base, "dn_maxpool_1x2: null pointer");
   DN_CHECK_ARG(x.channels == y.channels && N > 0 && H > 0 && Wout > 0, "dn_maxpool_1x2: bad shape");

@@ -7,12 +7,15 @@
 int conv_igemm_run_bf16_k35(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_bf16_k13(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_bf16_k11(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_bf16_k35_split(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_bf16_k11_split(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k35(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k13(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k11(const ConvParams& p, int ht, int cot, hipStream_t s);
 
 #include "conv_igemm8.h"
 int conv_igemm8_run_bf16(const ConvParams& p, int ht, hipStream_t s);
+int conv_igemm8_run_bf16_split(const ConvParams& p, int ht, hipStream_t s);
 int conv_igemm8_run_f32(const ConvParams& p, int ht, hipStream_t s);
 
 #include "conv_wgrad.h"

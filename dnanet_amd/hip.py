@@ -22,6 +22,11 @@ class DnTensor(Structure):
     _fields_ = [("base", c_void_p), ("planes_total", c_int), ("plane0", c_int), ("channels", c_int)]
 
 
+class DnTensorX3(Structure):
+    """``dn_tensor_x3``: a bf16 tensor kept as hi + lo parts ``lo_off`` planes apart (``lo_off`` = 0: plain bf16)."""
+    _fields_ = [("base", c_void_p), ("planes_total", c_int), ("plane0", c_int), ("channels", c_int), ("lo_off", c_int)]
+
+
 class DnPackJob(Structure):
     """``dn_pack_job`` of include/dnanet_hip.h."""
     _fields_ = [("w", c_void_p), ("scale", c_void_p), ("out", c_void_p), ("cout", c_int), ("cin", c_int), ("taps", c_int),
@@ -92,6 +97,10 @@ _SIGS = {
                                   c_int, c_int, _P]),
     "dn_bn_train_apply_pool": (c_int, [DnTensor, DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
                                   c_int, c_int, _P]),
+    "dn_conv2d_x3": (c_int, [DnTensorX3, _P, _P, DnTensorX3, POINTER(DnTensorX3)] + [c_int] * 6 + [_P]),
+    "dn_conv2d_head_x3": (c_int, [DnTensorX3, _P, _P, c_int, _P, _P, _P, _P] + [c_int] * 6 + [_P]),
+    "dn_conv_first_x3": (c_int, [_P, _P, _P, DnTensorX3] + [c_int] * 7 + [_P]),
+    "dn_conv_transpose_1x2_x3": (c_int, [DnTensorX3, _P, _P, DnTensorX3, c_int, c_int, c_int, _P]),
     "dn_call_alleles": (c_int, [_P, _P, _P, c_long, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
 }
 
@@ -175,6 +184,13 @@ class PlaneBuffer:
         assert plane0 + planes(channels, self.dtype) <= self.planes_total
         t = DnTensor(self.data.data_ptr(), self.planes_total, plane0, channels)
         t._owner = self      # a ref keeps its buffer alive (saved activations outlive the forward call)
+        return t
+
+    def ref3(self, channels: int, plane0: int = 0, lo_off: int = 0) -> DnTensorX3:
+        """hi + lo view (bf16 buffers only): hi planes from ``plane0``, lo planes ``lo_off`` further; 0 = plain tensor."""
+        assert self.dtype == BF16 and plane0 + lo_off + planes(channels, self.dtype) <= self.planes_total
+        t = DnTensorX3(self.data.data_ptr(), self.planes_total, plane0, channels, lo_off)
+        t._owner = self
         return t
 
     # conversions for tests / boundaries (torch ops, not on the hot path)

@@ -151,7 +151,7 @@ class _ResidentSet:
 class DNANet_UNet(TrainableModel):
     def __init__(self, depth: int, kernel_size: Tuple[int, int], num_filters: int = 64, device: Optional[str] = None,
                  apply_allele_caller: Optional[bool] = True, dtype: str = "fp32"):
-        """Same keywords as the reference (``trainable_unet.py:38-58``); ``dtype`` ("fp32" | "bf16") selects
+        """Same keywords as the reference (``trainable_unet.py:38-58``); ``dtype`` ("fp32" | "bf16" | inference only: "bf16x3", "bf16x3@<levels>") selects
         exact-fp32 MFMA (default, reference numerics) or bf16 MFMA with fp32 accumulation."""
         self._device = device or TORCH_DEFAULT_DEVICE
         # On a 'cpu' device only the parameter tree exists (checkpoint I/O, config plumbing); any forward raises.

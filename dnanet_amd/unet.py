@@ -30,9 +30,25 @@ def parse_dtype(dtype) -> int:
     if isinstance(dtype, int):
         return dtype
     try:
-        return _DTYPES[str(dtype).lower()]
+        return _DTYPES[str(dtype).lower().split("x3")[0]]
     except KeyError:
-        raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, got {dtype!r}")
+        raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, 'bf16x3' or 'bf16x3@<levels>', got {dtype!r}")
+
+
+def parse_split_levels(dtype, depth: int) -> int:
+    """``bf16x3``: every U-Net level keeps hi + lo bf16 activations and weights (three MFMAs per product: fp32-grade masks
+    from the bf16 matrix cores); ``bf16x3@k``: only the k shallowest levels (0..k-1), the deeper ones plain bf16.  0 for
+    every other dtype."""
+    name = str(dtype).lower()
+    if isinstance(dtype, int) or "x3" not in name:
+        return 0
+    head, _, tail = name.partition("x3")
+    if head not in ("bf16", "bfloat16") or (tail and not (tail[0] == "@" and tail[1:].isdigit())):
+        raise ValueError(f"dtype {dtype!r}: expected 'bf16x3' or 'bf16x3@<levels>'")
+    k = int(tail[1:]) if tail else depth + 1
+    if not 1 <= k <= depth + 1:
+        raise ValueError(f"dtype {dtype!r}: levels must be in [1, {depth + 1}]")
+    return k
 
 
 class HipUNet(ParameterTree):
@@ -45,6 +61,9 @@ class HipUNet(ParameterTree):
         if num_filters % 8:
             raise ValueError("num_filters must be a multiple of 8 for the MI355X kernels")
         self.dtype = parse_dtype(dtype)
+        self.split_levels = parse_split_levels(dtype, depth)       # > 0: the bf16x3 inference mode on that many levels
+        if self.split_levels and tuple(kernel_size) != (3, 5):
+            raise ValueError("dtype bf16x3 is built for kernel_size (3, 5) only")
         self._eval_cache = None
         self._eval_cache_version = None
         self.profile = None     # set to a list to collect (kernel tag, flops, start event, end event) per conv launch
@@ -118,7 +137,25 @@ class HipUNet(ParameterTree):
     # eval-mode (BatchNorm folded into the packed weights)
     # ------------------------------------------------------------------------------------------
     def _versions(self):
-        return (self.flat_params._version, self.flat_stats._version, self._param_epoch, self.dtype)
+        return (self.flat_params._version, self.flat_stats._version, self._param_epoch, self.dtype, self.split_levels)
+
+    def _unit_level(self, name: str) -> int:
+        """U-Net level (0 = full scan resolution) a convolution / up-convolution writes at."""
+        part, idx = name.split(".")[0], name.split(".")[1]
+        return self.depth if part == "bottleneck" else int(idx) if part == "encoders" else self.depth - 1 - int(idx)
+
+    def _split_terms(self, w: torch.Tensor, dim: int, split_input: bool) -> torch.Tensor:
+        """fp32 weight -> the virtual-input-channel image of the bf16x3 kernels: channels along ``dim`` padded to whole planes,
+        then [W_hi | W_hi | W_lo] (against the K walk [x_hi | x_lo | x_hi] of a split input) or [W_hi | W_lo] (plain input)."""
+        e = hip.epr(BF16)
+        pad = (-w.shape[dim]) % e
+        if pad:
+            shape = list(w.shape)
+            shape[dim] = pad
+            w = torch.cat([w, torch.zeros(shape, dtype=w.dtype, device=w.device)], dim)
+        hi = w.bfloat16().float()
+        lo = w - hi
+        return torch.cat([hi, hi, lo] if split_input else [hi, lo], dim).contiguous()
 
     @torch.no_grad()
     def _build_eval_cache(self):
@@ -136,11 +173,18 @@ class HipUNet(ParameterTree):
                 wf = torch.zeros((kh * kw, hip.channel_pad(u.cout)), dtype=torch.float32, device=self.device)
                 wf[:, :u.cout] = (w * scale.view(-1, 1, 1, 1)).reshape(u.cout, kh * kw).t()
                 entry["wf"] = wf
+            elif self._unit_level(u.conv) < self.split_levels:
+                wv = self._virtual_weight(u, w * scale.view(-1, 1, 1, 1))
+                entry["w"] = self._pack(self._split_terms(wv, 1, True), None, hip.PACK_FWD)
             else:
                 entry["w"] = self._pack(self._virtual_weight(u, w), scale.contiguous(), hip.PACK_FWD)
             cache[u.conv] = entry
         for up in self.up_units:
-            cache[up.name] = {"w": self._pack(self.tensor(up.name + ".weight"), None, hip.PACK_CONVT_FWD),
+            wu = self.tensor(up.name + ".weight")
+            level = self._unit_level(up.name)
+            if level < self.split_levels:
+                wu = self._split_terms(wu, 0, level + 1 < self.split_levels)
+            cache[up.name] = {"w": self._pack(wu, None, hip.PACK_CONVT_FWD),
                               "bias": self._up_bias2(self.tensor(up.name + ".bias"))}
         cache["head_w"] = self._padvec(self.tensor("outputs.weight"))
         cache["head_b"] = self.tensor("outputs.bias").clone()
@@ -237,6 +281,98 @@ class HipUNet(ParameterTree):
         hip.check(hip.lib.dn_head_1x1(cur.ref(c[0]), hip.ptr(cache["head_w"]), hip.ptr(cache["head_b"]),
                                       hip.ptr(logits), hip.ptr(probs), n, h, w, dt, hip.stream_ptr()))
 
+    @torch.no_grad()
+    def _forward_eval_chunk_x3(self, x: torch.Tensor, logits: Optional[torch.Tensor], probs: Optional[torch.Tensor]):
+        """The eval forward with hi + lo split tensors on the ``split_levels`` shallowest levels (``dn_*_x3``), plain bf16
+        below.  A split tensor of P planes occupies 2P planes of its buffer ([hi | lo]); a split concat buffer is
+        [up_hi | skip_hi | up_lo | skip_lo]."""
+        n, _, h, w = x.shape
+        depth, f, dt, dev = self.depth, self.num_filters, BF16, self.device
+        kh, kw = self.kernel_size
+        c = [f * 2 ** l for l in range(depth + 1)]
+        ws = [w >> l for l in range(depth + 1)]
+        P = [self._pp(ch) for ch in c]
+        S = lambda l: l < self.split_levels
+        cache = self._eval_cache
+        units = {u.conv: u for u in self.conv_units}
+        stream = hip.stream_ptr()
+
+        def act(l, chan_level, units_wide=1):
+            """buffer for `units_wide` tensors of c[chan_level] channels at level l's width and precision"""
+            return PlaneBuffer(n, units_wide * P[chan_level] * (2 if S(l) else 1), h, ws[l], dt, dev)
+
+        def r3(buf, l, channels, plane0, hi_planes):
+            return buf.ref3(channels, plane0, hi_planes if S(l) else 0)
+
+        def conv(name, l, src3, src, dst3, dst, pooled3=None, pooled=None):
+            u, entry = units[name], cache[name]
+            if self.profile is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if not S(l):
+                self._conv_launch(u, entry, src, dst, n, h, ws[l], 1, pooled)
+            elif u.cin == 1:
+                hip.check(hip.lib.dn_conv_first_x3(hip.ptr(src), hip.ptr(entry["wf"]), hip.ptr(entry["bias"]), dst3, n, h, ws[l],
+                                                   u.cout, kh, kw, 1, stream))
+            else:
+                hip.check(hip.lib.dn_conv2d_x3(src3, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), dst3,
+                                               ctypes.byref(pooled3) if pooled3 is not None else None, n, h, ws[l], kh, kw, 1, stream))
+            if self.profile is not None and u.cin != 1:
+                e1.record()
+                tag = ("x3:" if S(l) else "") + self.conv_kernel_tag(u.cin, u.cout, n, h, ws[l]) + ("+pool" if pooled3 is not None else "")
+                self.profile.append((tag, 2.0 * n * h * ws[l] * u.cout * u.cin * kh * kw, e0, e1))
+
+        cat = [act(l, l, 2) for l in range(depth)]
+        cur = x
+        for l in range(depth):
+            pre = f"encoders.{l}.conv.double_conv"
+            tmp = act(l, l)
+            conv(pre + ".0", l, None if l == 0 else r3(cur, l, c[l - 1], 0, P[l - 1]), cur if l == 0 else cur.ref(c[l - 1]),
+                 r3(tmp, l, c[l], 0, P[l]), tmp.ref(c[l]))
+            pooled = act(l + 1, l)
+            conv(pre + ".3", l, r3(tmp, l, c[l], 0, P[l]), tmp.ref(c[l]), r3(cat[l], l, c[l], P[l], 2 * P[l]), cat[l].ref(c[l], P[l]),
+                 r3(pooled, l + 1, c[l], 0, P[l]), pooled.ref(c[l]))
+            cur = pooled
+        pre = "bottleneck.double_conv"
+        tmp, out = act(depth, depth), act(depth, depth)
+        conv(pre + ".0", depth, r3(cur, depth, c[depth - 1], 0, P[depth - 1]), cur.ref(c[depth - 1]),
+             r3(tmp, depth, c[depth], 0, P[depth]), tmp.ref(c[depth]))
+        conv(pre + ".3", depth, r3(tmp, depth, c[depth], 0, P[depth]), tmp.ref(c[depth]),
+             r3(out, depth, c[depth], 0, P[depth]), out.ref(c[depth]))
+        cur = out
+        for i in range(depth):
+            l = depth - 1 - i
+            up = cache[f"decoders.{i}.up"]
+            if S(l):
+                hip.check(hip.lib.dn_conv_transpose_1x2_x3(r3(cur, l + 1, c[l + 1], 0, P[l + 1]), hip.ptr(up["w"]), hip.ptr(up["bias"]),
+                                                           r3(cat[l], l, c[l], 0, 2 * P[l]), n, h, ws[l + 1], stream))
+            else:
+                hip.check(hip.lib.dn_conv_transpose_1x2(cur.ref(c[l + 1]), hip.ptr(up["w"]), hip.ptr(up["bias"]),
+                                                        cat[l].ref(c[l], 0), n, h, ws[l + 1], dt, stream))
+            pre = f"decoders.{i}.conv.double_conv"
+            tmp = act(l, l)
+            cpad2 = 2 * self._cpad_planes(c[l])
+            conv(pre + ".0", l, r3(cat[l], l, cpad2, 0, 2 * P[l]), cat[l].ref(cpad2, 0), r3(tmp, l, c[l], 0, P[l]), tmp.ref(c[l]))
+            last = units[pre + ".3"]
+            if l == 0:
+                entry = cache[pre + ".3"]
+                if not hip.lib.dn_conv2d_head_supported(last.cin, last.cout, n, h, w, kh, kw, dt):
+                    raise hip.HipError(f"bf16x3: no fused-head kernel for {last.cout} output channels at N={n}, H={h}, W={w}")
+                if self.profile is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                hip.check(hip.lib.dn_conv2d_head_x3(r3(tmp, 0, c[0], 0, P[0]), hip.ptr(entry["w"]), hip.ptr(entry["bias"]), last.cout,
+                                                    hip.ptr(cache["head_w"]), hip.ptr(cache["head_b"]), hip.ptr(logits),
+                                                    hip.ptr(probs), n, h, w, kh, kw, 1, stream))
+                if self.profile is not None:
+                    e1.record()
+                    self.profile.append(("x3:" + self.conv_kernel_tag(last.cin, last.cout, n, h, w) + "+head",
+                                         2.0 * n * h * w * last.cout * (last.cin * kh * kw + 1), e0, e1))
+                return
+            out = act(l, l)
+            conv(pre + ".3", l, r3(tmp, l, c[l], 0, P[l]), tmp.ref(c[l]), r3(out, l, c[l], 0, P[l]), out.ref(c[l]))
+            cur = out
+
     def _check_input(self, x: torch.Tensor):
         self._require_gpu(x)
         if x.dim() != 4 or x.shape[1] != 1 or x.dtype != torch.float32:
@@ -256,7 +392,8 @@ class HipUNet(ParameterTree):
         probs = torch.empty_like(x) if want_probs else None
         for s in range(0, n, self.MAX_CHUNK):
             e = min(n, s + self.MAX_CHUNK)
-            self._forward_eval_chunk(x[s:e], logits[s:e] if want_logits else None, probs[s:e] if want_probs else None)
+            chunk = self._forward_eval_chunk_x3 if self.split_levels else self._forward_eval_chunk
+            chunk(x[s:e], logits[s:e] if want_logits else None, probs[s:e] if want_probs else None)
         return logits, probs
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -398,6 +535,8 @@ class HipUNet(ParameterTree):
 
     def forward_train(self, x: torch.Tensor) -> torch.Tensor:
         """Train-mode forward (batch statistics, running-stat update); keeps activations for backward()."""
+        if self.split_levels:
+            raise RuntimeError("dtype bf16x3 is an inference mode: train with dtype fp32 or bf16 and load the weights")
         self._check_input(x)
         x = x.contiguous()
         if self._train_cache is None or self._train_cache_version != self._versions():

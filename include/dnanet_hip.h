@@ -43,6 +43,17 @@ typedef struct dn_tensor {
   int channels;      /* logical channel count C */
 } dn_tensor;
 
+/* A bf16 tensor kept as hi + lo (bf16x3 inference mode): value = hi + lo with hi = bf16(v), lo = bf16(v - hi), i.e. ~16
+ * mantissa bits.  The lo part sits `lo_off` planes after the hi part in the same buffer (lo_off >= the tensor's planes, so
+ * that a concat buffer can hold [up_hi | skip_hi | up_lo | skip_lo]); lo_off = 0 marks a plain bf16 tensor. */
+typedef struct dn_tensor_x3 {
+  void* base;
+  int planes_total;
+  int plane0;
+  int channels;
+  int lo_off;
+} dn_tensor_x3;
+
 /* return codes (common.h has the same values under DN_OK / DN_ERR_*) */
 #define DN_STATUS_OK 0
 #define DN_STATUS_BAD_ARGUMENT 1
@@ -106,6 +117,27 @@ int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2,
  * DN_PACK_CONVT_DGRAD. */
 int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx, int N, int H, int Win, int dtype,
                                 void* stream);
+/* ---- bf16x3: the same eval-mode operators on hi + lo split bf16 tensors and weights ----------------
+ * fp32-grade results from the bf16 matrix cores: a product w*x is evaluated as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi (three
+ * bf16 MFMAs, fp32 accumulation; the dropped w_lo*x_lo term is 2^-18 relative), and every activation is written back as
+ * hi + lo by the epilogue.  Replaces the same torch operators as dn_conv2d / dn_conv2d_pool / dn_conv2d_head /
+ * dn_conv_first / dn_conv_transpose_1x2 above (unet_architecture.py:14-21,37,54-62,94-97) for callers that need the
+ * reference's fp32 masks at more than the fp32 matrix rate.  Storage is bf16; there is no dtype argument.
+ * packed_w is an ordinary DN_PACK_FWD (DN_PACK_CONVT_FWD) image over the VIRTUAL input channels, cin padded to whole planes:
+ *   split input (x.lo_off > 0): [W_hi | W_hi | W_lo]  against the K walk [x_hi | x_lo | x_hi]
+ *   plain input (x.lo_off = 0): [W_hi | W_lo]         against          [x    | x]
+ * (BatchNorm folded into W before the split).  Outputs are always split (y.lo_off >= planes of y); `pooled` may be plain. */
+int dn_conv2d_x3(dn_tensor_x3 x, const void* packed_w, const float* bias, dn_tensor_x3 y, const dn_tensor_x3* pooled, int N, int H,
+                 int W, int kh, int kw, int relu, void* stream);
+/* last DoubleConv convolution + 1x1 head + sigmoid on a split / plain input; the head sees the fp32 activation */
+int dn_conv2d_head_x3(dn_tensor_x3 x, const void* packed_w, const float* bias, int cout, const float* head_w, const float* head_b,
+                      float* logits, float* probs, int N, int H, int W, int kh, int kw, int relu, void* stream);
+/* first convolution (fp32 input, fp32 matrix cores as in dn_conv_first) with a split output */
+int dn_conv_first_x3(const float* x, const float* wf, const float* bias, dn_tensor_x3 y, int N, int H, int W, int cout, int kh,
+                     int kw, int relu, void* stream);
+int dn_conv_transpose_1x2_x3(dn_tensor_x3 x, const void* packed_w, const float* bias2, dn_tensor_x3 y, int N, int H, int Win,
+                             void* stream);
+
 /* nn.MaxPool2d((1,2)) (unet_architecture.py:37): y[n,c,h,w] = max(x[n,c,h,2w], x[n,c,h,2w+1]). */
 int dn_maxpool_1x2(dn_tensor x, dn_tensor y, int N, int H, int Wout, int dtype, void* stream);
 /* nn.Conv2d(C, 1, 1) head (unet_architecture.py:94-97) and torch.sigmoid (trainable_unet.py:409):
