@@ -49,6 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=256, help="profiles per GPU per step")
     ap.add_argument("--rows", type=int, default=6, help="dye rows (6 = BASELINE.json wording, 5 = reference HIDImage)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="precision of the headline leg")
+    # (the bf16x3 inference modes are reported as legs: infer_bf16x3_h6, infer_bf16x3@2_h6, infer_bf16x3_h5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline leg only (no fp32 / 5-dye legs, no parity counts)")
@@ -62,7 +63,7 @@ def parse_args(argv=None):
 
 
 def peak_of(dtype: str) -> float:
-    return BF16_PEAK_TFLOPS if dtype == "bf16" else F32_PEAK_TFLOPS
+    return BF16_PEAK_TFLOPS if dtype.startswith("bf16") else F32_PEAK_TFLOPS
 
 
 def spawn_ranks(args) -> int:
@@ -291,21 +292,24 @@ def parity_leg(dev, n=64):
     from dnanet_amd.synthetic import make_batch
     from dnanet_amd.unet import HipUNet
     x = torch.from_numpy(make_batch(n, 5, 4096, seed=4321, unique=n)[0]).to(dev)
-    out = {"what": f"bf16 kernels vs fp32 kernels, shipped config, {n} synthetic 5x4096 profiles; masks p >= 0.5, alleles by "
-                   "the NearestBasePairCaller hand-off"}
+    out = {"what": f"bf16 / bf16x3 (hi + lo split) / bf16x3@2 (split on the two shallowest levels) kernels vs fp32 kernels, shipped "
+                   f"config, {n} synthetic 5x4096 profiles; masks p >= 0.5, alleles by the NearestBasePairCaller hand-off"}
     states = {"briefly_trained": briefly_trained_state(4, (3, 5), 32, dev)}
     ref = make_eval_model("fp32", dev)
     states["random_init"] = {k: v.detach().cpu().clone() for k, v in ref.state_dict().items()}
     del ref
     for name, sd in states.items():
         probs = {}
-        for dtype in ("fp32", "bf16"):
+        for dtype in ("fp32", "bf16", "bf16x3", "bf16x3@2"):
             m = HipUNet(4, (3, 5), 32, dev, dtype=dtype)
             m.load_state_dict(sd)
             m.eval()
             probs[dtype] = m.infer(x, want_logits=False)[1]
             del m
         out[name] = disagreement(probs["bf16"], probs["fp32"], x)
+        for dtype in ("bf16x3", "bf16x3@2"):
+            out[name][dtype] = {k: v for k, v in disagreement(probs[dtype], probs["fp32"], x).items()
+                                if k in ("mask_pixels_differing", "alleles_differing", "profiles_with_allele_difference", "max_abs_prob_diff")}
     torch.cuda.empty_cache()
     return out
 
@@ -380,7 +384,7 @@ def main():
 
     common = (dev, rank, world, barrier, reduce_max)
     value, ms, roofline = infer_leg(args.dtype, args.rows, args.batch, args.steps, args.warmup, *common)
-    dt = lambda d: "bf16" if d == "bf16" else "f32"
+    dt = lambda d: d if d.startswith("bf16") else "f32"
     out = {
         "metric": "profiles/sec U-Net inference (pretrained-shape U-Net, batch 256 per GPU)",
         "value": round(value, 1), "unit": "profiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -396,8 +400,11 @@ def main():
         # the other halves of configs[1]: the reference's precision on the same batch, and the reference's HIDImage shape
         legs = {}
         other = "fp32" if args.dtype == "bf16" else "bf16"
+        # bf16x3: hi + lo split bf16 tensors, three MFMAs per product -- fp32-grade masks from the bf16 matrix cores (every
+        # level, or only the two shallowest: "bf16x3@2"); their roofline counts a product once (algorithmic FLOP)
         for name, (d, rows) in {f"infer_{dt(other)}_h{args.rows}": (other, args.rows), "infer_bf16_h5": ("bf16", 5),
-                                "infer_f32_h5": ("fp32", 5)}.items():
+                                "infer_f32_h5": ("fp32", 5), f"infer_bf16x3_h{args.rows}": ("bf16x3", args.rows),
+                                f"infer_bf16x3@2_h{args.rows}": ("bf16x3@2", args.rows), "infer_bf16x3_h5": ("bf16x3", 5)}.items():
             steps = max(3, args.steps // 4) if d == "fp32" else max(5, args.steps // 2)
             v, m, r = infer_leg(d, rows, args.batch, steps, min(2, args.warmup), *common)
             legs[name] = {"value": round(v, 1), "unit": "profiles/s", "dtype": dt(d), "rows": rows, "batch": args.batch,

@@ -235,6 +235,8 @@ class DNANet_UNet(TrainableModel):
             weight_decay: float = 0.0005, tensorboard: bool = False, validation_set=None,
             min_delta: Optional[float] = 0.01, steps_per_epoch: Optional[int] = None, use_evaluation_metric: bool = True,
             checkpoint_dir=None, save_best: bool = False, use_scheduler: bool = False, **kwargs):
+        if self._model.split_levels:
+            raise RuntimeError("dtype bf16x3 is an inference mode: train with dtype fp32 or bf16 and load the checkpoint")
         if save_best:
             if validation_set is None:
                 raise TypeError("`validation_set` is required when `save_best` is True")

@@ -62,6 +62,31 @@ def test_predict_batch_bf16_mask_agreement(gpu_device):
     assert agree > 0.995, agree       # bf16 mode: reported agreement, not identity
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16x3@2"])
+def test_predict_batch_bf16x3_masks_and_alleles_of_the_reference(gpu_device, dtype):
+    """The real RD profiles through predict_batch in the hi + lo split bf16 modes: the reference's masks and called alleles,
+    probabilities to 3e-4 (plain bf16: agreement only, see above); fit() refuses the inference-only dtype."""
+    from dnanet_amd.allele_caller import NearestBasePairCaller
+    from dnanet_amd.data import Panel
+    from dnanet_amd.model import DNANet_UNet
+    g = load_golden("g_real_d4_k35_f8")
+    panel = Panel(os.path.join(GOLDEN_DIR, "panel.xml"))
+    model = DNANet_UNet(4, (3, 5), 8, device="cuda", apply_allele_caller=True, dtype=dtype)
+    model._model.load_state_dict(g["sd0"])
+    images = _images(g["x"], g["t"], panel)
+    preds = model.predict_batch(images)
+    ref_probs = torch.sigmoid(torch.from_numpy(g["logits_eval"])).numpy()
+    key = lambda ms: sorted((m.dye_row, m.name, tuple(sorted((a.name, a.height) for a in m.alleles))) for m in ms)
+    for i, p in enumerate(preds):
+        ref = np.transpose(ref_probs[i], (1, 2, 0))
+        assert np.abs(p.image - ref).max() < (3e-4 if dtype == "bf16x3" else 2e-3)
+        assert np.array_equal(p.image >= 0.5, ref >= 0.5)
+        expect = NearestBasePairCaller().translate_pixels_to_alleles(images[i]._scaler[None], ref, images[i].data, panel)
+        assert key(p.meta["called_alleles"]) == key(expect)
+    with pytest.raises(RuntimeError, match="inference mode"):
+        model.fit(images, num_epochs=1, batch_size=2)
+
+
 def test_fit_loop_matches_oracle_loop(gpu_device):
     """fit(): chunking, dropped remainder, per-epoch ExponentialLR, Adam -- against the oracle's restatement of the
     reference loop (trainable_unet.py:183-203,273-274,339-347)."""
