@@ -81,3 +81,37 @@ def test_adam_matches_torch():
         opt.step()
         O.adam_step(sd, {"p": g}, st, 1e-2, 5e-4)
     assert torch.allclose(sd["p"], ref.data, rtol=1e-6, atol=1e-7)
+
+
+def _shipped():
+    import os
+    from conftest import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "shipped_d4_k35_f32.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def test_shipped_config_vs_reference():
+    """The shipped configuration (depth 4, (3,5), 32 filters; 12 123 745 parameters) against outputs of the reference's own
+    UNet / DiceLoss on seeded weights (tests/golden/make_golden_shipped.py): eval logits, train-mode logits, loss, and of
+    every parameter gradient its norm, sum and first 256 elements."""
+    g = _shipped()
+    sd = O.init_state_dict(4, (3, 5), 32, seed=int(g["seed"]), randomize_bn_stats=True)
+    assert sum(v.numel() for k, v in sd.items() if k in O.trainable_keys(sd)) == int(g["n_params"]) == 12123745
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
+    ref = torch.from_numpy(g["logits_eval"])
+    assert torch.allclose(O.unet_forward(sd, x, train=False), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    state = O.AdamState(O.trainable_keys(sd), sd)
+    loss, logits, grads = O.train_step(sd, x, t, state, 1e-4, 5e-4)
+    assert abs(loss - float(g["step0/loss"])) < 2e-6
+    ref = torch.from_numpy(g["step0/logits"])
+    assert torch.allclose(logits, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    for k, gr in grads.items():
+        norm = float(g["gnorm/" + k])
+        if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
+            continue                      # mathematically zero (bias in front of BatchNorm): rounding noise on both sides
+        assert abs(float(gr.double().norm()) - norm) <= 2e-4 * norm, k
+        head = torch.from_numpy(g["ghead/" + k])
+        assert float((gr.reshape(-1)[:256] - head).abs().max()) <= 5e-4 * float(gr.abs().max()), k
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.allclose(sd[k], torch.from_numpy(g["stats1/" + k]), rtol=1e-4, atol=1e-5), k
