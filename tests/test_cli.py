@@ -60,6 +60,15 @@ def test_config_registry(tmp_path, monkeypatch):
     metrics = load_evaluation_config("segmentation")
     assert list(metrics) == ["pixel_precision", "pixel_recall", "pixel_f1_score", "average_binary_iou_threshold_0.5"]
     assert metrics["average_binary_iou_threshold_0.5"].keywords == {"threshold": 0.5}
+    # the shipped model configs parse into the model class with the precision they name (parameter tree only on the CPU)
+    from dnanet_amd.config_io import load_model
+    for name, (dtype, split) in {"unet": (0, 0), "unet_bf16": (1, 0), "unet_bf16x3": (1, 5)}.items():
+        cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "models", name + ".yaml")))
+        cfg["model"]["device"] = "cpu"
+        path = tmp_path / (name + ".yaml")
+        path.write_text(yaml.safe_dump(cfg))
+        m = load_model(str(path))
+        assert (m._model.dtype, m._model.split_levels, m._model.num_filters) == (dtype, split, 32)
 
 
 def test_cli_flags_match_the_reference():
@@ -100,6 +109,12 @@ def test_train_evaluate_cross_validate_end_to_end(tmp_path, monkeypatch, gpu_dev
     assert set(res) >= {"pixel_precision", "pixel_recall", "pixel_f1_score"}
     preds = json.load(open(ev / "predictions.json"))
     assert len(preds) == 3 and np.array(preds[0]["image"]).shape == (5, 256, 1)
+    # the same fp32-trained checkpoint evaluated through the hi + lo split bf16 kernels: the same masks, hence the same metrics
+    (cfg / "model_x3.yaml").write_text(yaml.safe_dump({"model": {"name": "unet", "depth": 2, "kernel_size": [3, 5], "num_filters": 8,
+                                                                 "apply_allele_caller": False, "device": "cuda", "dtype": "bf16x3"}}))
+    res3 = evaluate.run(str(cfg / "data.yaml"), str(cfg / "model_x3.yaml"), os.path.join(ROOT, "config/evaluation/segmentation.yaml"),
+                        output_dir=str(tmp_path / "eval_x3"), checkpoint_dir=str(out), save_preds=False, split=0.25, seed=1)
+    assert res3.keys() == res.keys() and all(abs(res3[k] - res[k]) < 2e-3 or (np.isnan(res3[k]) and np.isnan(res[k])) for k in res)
     cv = tmp_path / "cv"
     agg = cross_validate.run(str(cfg / "data.yaml"), str(cfg / "model.yaml"), str(cfg / "train.yaml"),
                              os.path.join(ROOT, "config/evaluation/segmentation.yaml"), 3, output_dir=str(cv))
