@@ -39,7 +39,9 @@ def per_kernel(counter, d):
     return tot[name] / max(cnt[name], 1) * 1024.0
 
 fetch, write = per_kernel("FETCH_SIZE", "pmc_fetch"), per_kernel("WRITE_SIZE", "pmc_write")
-rec = {"kernel": infer_line["roofline"]["kernel"], "rocprof_kernel_name": name,
+sys.path.insert(0, ROOT)
+from bench import kernel_source_digest  # noqa: E402  (the sources the dominant kernel is compiled from)
+rec = {"kernel": infer_line["roofline"]["kernel"], "rocprof_kernel_name": name, "kernel_source_sha256": kernel_source_digest(),
        "rocprof_avg_launch_us": float(dominant["AverageNs"]) / 1e3, "bench_avg_launch_us": infer_line["roofline"]["avg_launch_us"],
        "fetch_size_bytes_per_launch_raw": fetch, "fetch_size_bytes_per_launch_corrected": 2 * fetch,
        "write_size_bytes_per_launch": write, "traffic_bytes_per_launch": 2 * fetch + write,
