@@ -74,3 +74,26 @@ if os.path.isfile(mf):
             f.write(f'"{k}",{launches[k]},{util:.3f},{m / max(launches[k], 1):.0f},{per(c["SQ_INSTS_VALU"])},'
                     f'{per(c["SQ_INSTS_LDS"])},{c["SQ_WAIT_INST_ANY"] / max(c["SQ_WAVE_CYCLES"], 1.0):.2f}\n')
     print(open(os.path.join(P, f"{tag}_mfma_utilisation_per_kernel.csv")).read()[:3000])
+
+# achieved HBM bandwidth per kernel (north-star: "achieved HBM GB/s against MI355X peak" for the memory-bound stages): measured
+# traffic per launch (2 x FETCH_SIZE + WRITE_SIZE of the counter passes) over the average duration of the single-stream
+# kernel-trace pass (DN_TUNE_NO_WGRAD_STREAM=1: with the weight gradients on a second stream, overlapping kernels stretch each other)
+def per_launch(counter, d):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(os.path.join(G, d, "p_counter_collection.csv"))):
+        if r["Counter_Name"] == counter:
+            tot[r["Kernel_Name"]] += float(r["Counter_Value"]) * 1024.0; cnt[r["Kernel_Name"]] += 1
+    return {k: tot[k] / cnt[k] for k in tot}
+fe, wr = per_launch("FETCH_SIZE", "pmc_fetch"), per_launch("WRITE_SIZE", "pmc_write")
+one = os.path.join(G, "prof_full_1stream", "p_kernel_stats.csv")       # single-stream pass: durations not stretched by overlap
+full = {r["Name"]: r for r in csv.DictReader(open(one if os.path.isfile(one) else os.path.join(G, "prof_full", "p_kernel_stats.csv")))}
+with open(os.path.join(P, f"{tag}_hbm_bandwidth_per_kernel.csv"), "w") as f:
+    f.write("kernel,launches,avg_launch_us,hbm_read_MB_per_launch,hbm_write_MB_per_launch,achieved_GB_per_s,frac_of_8_TB_per_s,share_of_run_time_pct\n")
+    for k, r in sorted(full.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"]))[:30]:
+        if k not in fe:
+            continue
+        us = float(r["AverageNs"]) / 1e3
+        rd, w_ = 2 * fe[k], wr.get(k, 0.0)
+        gbs = (rd + w_) / us / 1e3
+        f.write(f'"{k}",{r["Calls"]},{us:.1f},{rd / 1e6:.1f},{w_ / 1e6:.1f},{gbs:.0f},{gbs / 8000:.3f},{float(r["Percentage"]):.2f}\n')
+print(open(os.path.join(P, f"{tag}_hbm_bandwidth_per_kernel.csv")).read())
