@@ -100,7 +100,10 @@ __device__ __forceinline__ double wave_sum_partials(const float* partial, int nb
 // RED_SEG pieces and the (image, segment) units are dealt round-robin to the blocks of a plane.  A thread reads four
 // pieces 256 apart per step (independent loads in flight: a single dependent load per thread left HBM at ~4 TB/s);
 // its piece parity, hence its channels, is fixed (threadIdx.x & 1).
-constexpr int BWD_ILP = 4;         // bn_bwd_reduce_kernel: loads of g and of y in flight per thread (2 left HBM at 4.9 TB/s)
+#ifndef DN_BWD_ILP
+#define DN_BWD_ILP 4
+#endif
+constexpr int BWD_ILP = DN_BWD_ILP;         // bn_bwd_reduce_kernel: loads of g and of y in flight per thread (2 left HBM at 4.9 TB/s)
 constexpr int RED_SEG = 4096;      // pieces per unit at large batch; red_seg() shrinks it when there are few images
 
 template <typename T>

@@ -15,7 +15,8 @@ F32, BF16 = 0, 1
 PACK_FWD, PACK_DGRAD, PACK_CONVT_FWD, PACK_CONVT_DGRAD = 0, 1, 2, 3
 PACK_VEC, PACK_UP_BIAS, PACK_FIRST = 4, 5, 6          # fp32 side images, dn_pack_batched only
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdnanet_hip.so")
+# DNANET_HIP_LIB: another build of the same library (A/B runs of scratch/ micro-benchmarks); default = the in-tree build
+_LIB_PATH = os.environ.get("DNANET_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdnanet_hip.so")
 
 
 class DnTensor(Structure):
