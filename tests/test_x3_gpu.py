@@ -48,7 +48,8 @@ def pack(w, cout, cin, kh, kw, mode):
 
 @pytest.mark.parametrize("n,h,w,cin,cout,split_in,pool", [(2, 5, 256, 32, 64, True, True), (3, 6, 128, 64, 32, True, False),
                                                            (2, 5, 512, 48, 64, False, False), (16, 5, 256, 64, 64, True, True),
-                                                           (2, 3, 384, 16, 32, True, True), (1, 4, 128, 40, 24, True, False)])
+                                                           (2, 3, 384, 16, 32, True, True), (1, 4, 128, 40, 24, True, False),
+                                                           (2, 5, 160, 32, 32, True, True), (1, 7, 96, 64, 128, False, True), (300, 1, 64, 32, 64, True, False)])
 def test_conv2d_x3_vs_torch(gpu_device, n, h, w, cin, cout, split_in, pool):
     torch.manual_seed(cin + cout)
     dev = gpu_device
