@@ -48,7 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="profiles per GPU per step")
     ap.add_argument("--rows", type=int, default=6, help="dye rows (6 = BASELINE.json wording, 5 = reference HIDImage)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="precision of the headline leg")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x3@2"],
+                    help="precision of the headline leg (bf16x3*: inference-only hi + lo split bf16; the training legs then run in bf16)")
     # (the bf16x3 inference modes are reported as legs: infer_bf16x3_h6, infer_bf16x3@2_h6, infer_bf16x3_h5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
@@ -420,12 +421,11 @@ def main():
     if not args.no_legs and not distributed:
         # the other halves of configs[1]: the reference's precision on the same batch, and the reference's HIDImage shape
         legs = {}
-        other = "fp32" if args.dtype == "bf16" else "bf16"
         # bf16x3: hi + lo split bf16 tensors, three MFMAs per product -- fp32-grade masks from the bf16 matrix cores (every
         # level, or only the two shallowest: "bf16x3@2"); their roofline counts a product once (algorithmic FLOP)
-        for name, (d, rows) in {f"infer_{dt(other)}_h{args.rows}": (other, args.rows), "infer_bf16_h5": ("bf16", 5),
-                                "infer_f32_h5": ("fp32", 5), f"infer_bf16x3_h{args.rows}": ("bf16x3", args.rows),
-                                f"infer_bf16x3@2_h{args.rows}": ("bf16x3@2", args.rows), "infer_bf16x3_h5": ("bf16x3", 5)}.items():
+        todo = {f"infer_{dt(d)}_h{args.rows}": (d, args.rows) for d in ("fp32", "bf16", "bf16x3", "bf16x3@2") if d != args.dtype}
+        todo.update({f"infer_{dt(d)}_h5": (d, 5) for d in ("bf16", "fp32", "bf16x3") if (d, 5) != (args.dtype, args.rows)})
+        for name, (d, rows) in todo.items():
             steps = max(3, args.steps // 4) if d == "fp32" else max(5, args.steps // 2)
             v, m, r = infer_leg(d, rows, args.batch, steps, min(2, args.warmup), *common)
             legs[name] = {"value": round(v, 1), "unit": "profiles/s", "dtype": dt(d), "rows": rows, "batch": args.batch,
@@ -434,6 +434,8 @@ def main():
         out["parity"] = parity_leg(dev)
     if not args.no_train:
         tsteps = max(3, args.steps // 4)
+        if args.dtype.startswith("bf16x3"):
+            args.dtype = "bf16"            # inference-only precision: the training legs are the bf16 ones
         out["train_step"] = train_leg(args.dtype, args.rows, args.batch, tsteps, dev, rank, world, distributed, barrier, reduce_max)
         if distributed and args.global_batch % world == 0:
             # configs[3]: the same global batch on 2 / 4 / 8 GPUs (strong scaling of the training step)
