@@ -147,18 +147,35 @@ class NearestBasePairCaller:
                                               hip.stream_ptr()))
             peak, first = out.cpu().numpy()
             tables = {dye: self._table(panel, dye) for dye in range(h) if dye in panel.dye_bp_to_allele_mapping}
+            names = [tables[d].names if d in tables else [] for d in range(h)]
+            # A (marker, allele) name that the panel lists once has exactly one (dye, table row): its height is that row's
+            # peak and no second dictionary is needed (every kit table seen so far; the general path below keeps the
+            # reference's max over equal names)
+            all_names = [nm for t in tables.values() for nm in t.names]
+            unique_names = len(set(all_names)) == len(all_names)
             for k, i in enumerate(idx):
                 dyes, js = np.nonzero(first[k] != ABSENT)
                 order = np.lexsort((first[k][dyes, js], dyes))       # dye rows in order, runs left to right
-                loci: Dict[Tuple[int, str], Dict[str, None]] = {}
-                rfus: Dict[Tuple[str, str], int] = {}
-                for d, j in zip(dyes[order].tolist(), js[order].tolist()):
-                    marker_name, allele_name = tables[d].names[j]
-                    loci.setdefault((d, marker_name), {})[allele_name] = None
-                    key = (marker_name, allele_name)
-                    rfus[key] = max(rfus.get(key, 0), int(peak[k, d, j]))
-                called = [Marker(dye, marker_name, alleles=[Allele(name=a, height=rfus[(marker_name, a)]) for a in alleles])
-                          for (dye, marker_name), alleles in loci.items()]
+                dyes, js = dyes[order], js[order]
+                if unique_names:
+                    by_locus: Dict[Tuple[int, str], List[Allele]] = {}
+                    for d, j, p in zip(dyes.tolist(), js.tolist(), peak[k][dyes, js].tolist()):
+                        marker_name, allele_name = names[d][j]
+                        slot = by_locus.get((d, marker_name))
+                        if slot is None:
+                            slot = by_locus[(d, marker_name)] = []
+                        slot.append(Allele(name=allele_name, height=p if p > 0 else 0))
+                    called = [Marker(dye, marker_name, alleles=alleles) for (dye, marker_name), alleles in by_locus.items()]
+                else:
+                    loci: Dict[Tuple[int, str], Dict[str, None]] = {}
+                    rfus: Dict[Tuple[str, str], int] = {}
+                    for d, j in zip(dyes.tolist(), js.tolist()):
+                        marker_name, allele_name = names[d][j]
+                        loci.setdefault((d, marker_name), {})[allele_name] = None
+                        key = (marker_name, allele_name)
+                        rfus[key] = max(rfus.get(key, 0), int(peak[k, d, j]))
+                    called = [Marker(dye, marker_name, alleles=[Allele(name=a, height=rfus[(marker_name, a)]) for a in alleles])
+                              for (dye, marker_name), alleles in loci.items()]
                 if "called_alleles_manual" in images[i].meta:
                     called = [m for m in called if m.name not in NON_AUTOSOMAL_MARKERS]
                 predictions[i].meta["called_alleles"] = called
