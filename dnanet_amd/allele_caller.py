@@ -122,12 +122,18 @@ class NearestBasePairCaller:
     def call_alleles_batch(self, images, predictions, probs, rfu):
         """``call_alleles`` for a whole batch.  ``probs`` / ``rfu``: (N,1,H,W) fp32 device tensors (probabilities of this
         batch, the raw inputs they were computed from).  Profiles are grouped by panel; every group is one launch."""
+        return self.finish_alleles_batch(images, predictions, self.launch_alleles_batch(images, probs, rfu))
+
+    def launch_alleles_batch(self, images, probs, rfu) -> list:
+        """Device half of ``call_alleles_batch``: queues the allele kernel(s) and the copy of their small tables into pinned
+        host memory; waits for nothing.  Returns the handle ``finish_alleles_batch`` takes."""
         import torch
         from . import hip
         n, _, h, w = probs.shape
         groups: Dict[int, List[int]] = {}
         for i, im in enumerate(images):
             groups.setdefault(id(im._panel), []).append(i)
+        handle = []
         for idx in groups.values():
             panel = images[idx[0]]._panel
             tb, to, toff, amax = self._device_tables(panel, h, probs.device)
@@ -140,12 +146,32 @@ class NearestBasePairCaller:
                 np.stack([np.asarray(sc, dtype=np.float64).reshape(-1) for sc in scalers])
             if sc_np.shape[1] != w:
                 raise ValueError(f"scaler has {sc_np.shape[1]} entries for {w} scan columns")
-            sc_dev = torch.from_numpy(np.ascontiguousarray(sc_np)).to(probs.device)
+            sc_cache = self.__dict__.setdefault("_dev_scalers", {})
+            sc_key = (id(scalers[0]), str(probs.device)) if shared else None
+            if sc_key in sc_cache and sc_cache[sc_key][0] is scalers[0]:
+                sc_dev = sc_cache[sc_key][1]                 # the base-pair axis every profile of a dataset shares: sent once
+            else:
+                sc_dev = torch.from_numpy(np.ascontiguousarray(sc_np)).to(probs.device)
+                if shared:
+                    if len(sc_cache) >= 16:
+                        sc_cache.clear()
+                    sc_cache[sc_key] = (scalers[0], sc_dev)
             out = torch.empty((2, len(idx), h, amax), dtype=torch.int32, device=probs.device)
             hip.check(hip.lib.dn_call_alleles(hip.ptr(p_sel), hip.ptr(x_sel), hip.ptr(sc_dev), 0 if shared else w, hip.ptr(tb),
                                               hip.ptr(to), hip.ptr(toff), len(idx), h, w, amax, hip.ptr(out[0]), hip.ptr(out[1]),
                                               hip.stream_ptr()))
-            peak, first = out.cpu().numpy()
+            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            handle.append((idx, panel, h, host, event, (p_sel, x_sel, sc_dev, out)))     # device operands alive until the copy is done
+        return handle
+
+    def finish_alleles_batch(self, images, predictions, handle: list):
+        """Host half: the per-(dye, allele) tables -> ``Marker`` / ``Allele`` objects in the reference's order."""
+        for idx, panel, h, host, event, _keep in handle:
+            event.synchronize()
+            peak, first = host.numpy()
             tables = {dye: self._table(panel, dye) for dye in range(h) if dye in panel.dye_bp_to_allele_mapping}
             names = [tables[d].names if d in tables else [] for d in range(h)]
             # A (marker, allele) name that the panel lists once has exactly one (dye, table row): its height is that row's

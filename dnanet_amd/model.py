@@ -466,33 +466,72 @@ class DNANet_UNet(TrainableModel):
     def predict(self, image) -> Prediction:
         return self.predict_batch([image])[0]
 
+    PREDICT_SUB_BATCH = 64     # profiles per pipeline stage of predict_batch (the kernels are at 95 % of their batch-256 rate)
+
     def predict_batch(self, batch: Sequence) -> List[Prediction]:
+        """``trainable_unet.py:371-409`` as a pipeline over sub-batches: stage k's tensorisation, H->D copy, forward, on-device
+        pixel counts, allele kernel and D->H copies (into pinned memory, asynchronous) are queued while the host is still
+        turning stage k-1's small tables into ``Prediction`` / ``Marker`` objects; at most two stages are in flight."""
         self._model.eval()
         batch = list(batch)
-        inputs = self.get_inputs(batch)
-        _, probs = self._model.infer(inputs, want_logits=False, want_probs=True)
-        host = probs.movedim(1, -1).cpu().numpy()                      # (N,H,W,1): one D->H copy for the batch
-        predictions = [Prediction(image=host[i], meta={"original_image_path": getattr(image, "path", None)})
-                       for i, image in enumerate(batch)]
-        counts = self._pixel_counts(batch, probs)
-        if counts is not None:       # annotated profiles: the pixel metrics' confusion counts from the same pass
-            for i, pred in enumerate(predictions):
-                if counts[i, 6] == 0:                 # a 0/1 mask
-                    pred._pixel_counts = (id(batch[i]), 0.5, tuple(int(c) for c in counts[i, :6]))
         if self.allele_caller:
             LOGGER.info("Calling alleles from predicted segmentation...")
-            if hasattr(self.allele_caller, "call_alleles_batch"):
-                # device path: runs / nearest base pair / peak heights from the probability maps still in HBM
-                predictions = self.allele_caller.call_alleles_batch(batch, predictions, probs, inputs)
-            else:
-                predictions = [self.allele_caller.call_alleles(im, pred) for im, pred in zip(batch, predictions)]
+        predictions: List[Prediction] = []
+        in_flight: List[tuple] = []
+        for s in range(0, len(batch), self.PREDICT_SUB_BATCH):
+            sub = batch[s:s + self.PREDICT_SUB_BATCH]
+            in_flight.append((sub, self._predict_launch(sub)))
+            if len(in_flight) > 2:
+                predictions += self._predict_finish(*in_flight.pop(0))
+        while in_flight:
+            predictions += self._predict_finish(*in_flight.pop(0))
         return predictions
 
-    def _pixel_counts(self, batch: Sequence, probs: torch.Tensor) -> Optional[np.ndarray]:
+    @staticmethod
+    def _to_pinned(t: torch.Tensor) -> torch.Tensor:
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        return host
+
+    def _predict_launch(self, sub: Sequence) -> dict:
+        """Queue everything one sub-batch needs on the GPU; nothing here waits for the device."""
+        inputs = self.get_inputs(sub)
+        _, probs = self._model.infer(inputs, want_logits=False, want_probs=True)
+        h = {"probs_host": self._to_pinned(probs.movedim(1, -1)), "counts_host": None, "alleles": None}    # (N,H,W,1)
+        counts = self._pixel_counts_launch(sub, probs)
+        if counts is not None:
+            h["counts_host"] = self._to_pinned(counts)
+        if self.allele_caller and hasattr(self.allele_caller, "launch_alleles_batch"):
+            # device path: runs / nearest base pair / peak heights from the probability maps still in HBM
+            h["alleles"] = self.allele_caller.launch_alleles_batch(sub, probs, inputs)
+        h["keep"] = (inputs, probs, counts)          # alive until the copies have been waited for
+        h["event"] = torch.cuda.Event()
+        h["event"].record()
+        return h
+
+    def _predict_finish(self, sub: Sequence, h: dict) -> List[Prediction]:
+        h["event"].synchronize()
+        host = h["probs_host"].numpy().copy()        # own memory: the pinned block goes back to the allocator
+        predictions = [Prediction(image=host[i], meta={"original_image_path": getattr(image, "path", None)})
+                       for i, image in enumerate(sub)]
+        if h["counts_host"] is not None:     # annotated profiles: the pixel metrics' confusion counts from the same pass
+            counts = h["counts_host"].numpy()
+            for i, pred in enumerate(predictions):
+                if counts[i, 6] == 0:                 # a 0/1 mask
+                    pred._pixel_counts = (id(sub[i]), 0.5, tuple(int(c) for c in counts[i, :6]))
+        if self.allele_caller:
+            if h["alleles"] is not None:
+                predictions = self.allele_caller.finish_alleles_batch(sub, predictions, h["alleles"])
+            else:
+                predictions = [self.allele_caller.call_alleles(im, pred) for im, pred in zip(sub, predictions)]
+        h["keep"] = None
+        return predictions
+
+    def _pixel_counts_launch(self, batch: Sequence, probs: torch.Tensor) -> Optional[torch.Tensor]:
         """On-device metrics: per profile {tp, fp, fn} at ``p >= 0.5`` and at ``p > 0.5`` against the
         annotation, computed from the probability maps while they are in HBM (``dn_pixel_confusion``).  Only for
         annotations that are 0/1 masks of the output's shape; for the others ``dnanet_amd.metrics`` makes its boolean
-        passes on the host, like the reference."""
+        passes on the host, like the reference.  Returns the (N,7) int32 device tensor, or None."""
         try:
             truth = np.stack([np.asarray(im.annotation.image) for im in batch])              # (N,H,W,1)
         except (AttributeError, ValueError, TypeError):
@@ -507,11 +546,15 @@ class DNANet_UNet(TrainableModel):
         else:
             truth = truth.astype(np.int8, copy=False)            # uint8 values >= 128 wrap to negatives: still "other"
         truth = np.ascontiguousarray(np.transpose(truth, (0, 3, 1, 2)))
-        truth_dev = torch.from_numpy(truth).to(probs.device)
+        truth_dev = torch.from_numpy(truth).to(probs.device, non_blocking=True)
         counts = torch.empty((len(batch), 7), dtype=torch.int32, device=probs.device)
         hip.check(hip.lib.dn_pixel_confusion(hip.ptr(probs), hip.ptr(truth_dev), len(batch), probs[0].numel(), 0.5, 0.5,
                                              hip.ptr(counts), hip.stream_ptr()))
-        return counts.cpu().numpy()
+        return counts
+
+    def _pixel_counts(self, batch: Sequence, probs: torch.Tensor) -> Optional[np.ndarray]:
+        counts = self._pixel_counts_launch(batch, probs)
+        return None if counts is None else counts.cpu().numpy()
 
     def predict_raw(self, images: Sequence) -> torch.Tensor:
         return self._model(self.get_inputs(images))

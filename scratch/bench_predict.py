@@ -9,6 +9,7 @@ panel = Panel(os.path.join(ROOT, 'tests/golden/panel.xml'))
 for im in ds:
     im._scaler = np.linspace(65, 475, 4096); im._panel = panel
 for caller in (False, True):
+    torch.manual_seed(0)
     m = DNANet_UNet(4, (3, 5), 32, device='cuda', apply_allele_caller=caller, dtype='bf16')
     # make the random-init net fire on ~3% of pixels so the caller has runs to chew on: bias the head
     with torch.no_grad():
@@ -17,6 +18,7 @@ for caller in (False, True):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     preds = m.predict_batch(ds)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); preds = m.predict_batch(ds); torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
     npos = float(np.mean([(p.image >= 0.5).mean() for p in preds[:8]]))
     ncall = sum(len(mk.alleles) for p in preds[:8] for mk in p.meta.get('called_alleles', [])) / 8 if caller else 0
     print(f'predict_batch N={n} allele_caller={caller}: {dt*1e3:.1f} ms  {n/dt:.0f} profiles/s  (positive px {npos:.3f}, alleles/profile {ncall:.1f})')
