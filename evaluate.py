@@ -17,7 +17,8 @@ def run(data_config, model_config, evaluation_config=None, output_dir=None, chec
         import torch
         import torch.distributed as dist
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            # (more ranks than GPUs -- a rehearsal on a small box -- share the devices round robin: nothing here needs RCCL)
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         if not dist.is_initialized():
             # before the dataset is split: an unseeded split is agreed on through the group (dnanet_amd.data.shared_seed).
             # gloo: the only exchanges are that seed and the ordered gather of host objects

@@ -19,9 +19,16 @@ def run(data_config, model_config, training_config, split=None, output_dir=None,
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # DNANET_DIST_BACKEND=gloo: rehearsal of the multi-rank path with ranks sharing a GPU (RCCL wants a device per rank);
+        # collectives on device tensors are then staged through the host (dnanet_amd/distributed.py)
+        backend = os.environ.get("DNANET_DIST_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local if backend == "nccl" else local % max(1, torch.cuda.device_count()))
         if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+            else:
+                dist.init_process_group(backend)
         if not output_dir:                              # the default name carries a timestamp: rank 0 picks it
             from datetime import datetime
             box = [os.path.join("output", f"train_{datetime.now().strftime('%Y-%m-%d_%H-%M-%S')}")]
