@@ -62,10 +62,10 @@ def test_shipped_config_train_step_vs_oracle(gpu_device):
 def test_batch256_inference_is_batch_invariant(gpu_device):
     from dnanet_amd.synthetic import make_batch
     from dnanet_amd.unet import HipUNet
-    for dtype in ("bf16", "fp32"):
+    for dtype in ("bf16", "fp32", "bf16x3", "bf16x3@2"):
         m = HipUNet(4, (3, 5), 32, gpu_device, dtype=dtype)
         m.eval()
-        n = 256 if dtype == "bf16" else 64
+        n = 64 if dtype == "fp32" else 256
         x = torch.from_numpy(make_batch(n, 6, 4096, seed=5, unique=8)[0]).to(gpu_device)
         full = m(x)
         for i in (0, 3, n - 1):
