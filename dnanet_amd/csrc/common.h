@@ -52,6 +52,7 @@ struct DnTune {
   bool no_head_fuse;    // DN_TUNE_NO_HEAD_FUSE: dn_conv2d_head_supported() says no
   long wgrad_blocks;    // DN_TUNE_WGRAD_BLOCKS: split-K target grid size (0 = default 512)
   int wgrad_noskip;     // DN_TUNE_WGRAD_NOSKIP: 1 = multiply the zero halo rows too, 2 = interleaved tap map
+  bool wgrad_no_cot32;  // DN_TUNE_WGRAD_NO_COT32: 64-wide output-channel tile also for layers with <= 32 output channels
   bool wgrad_no_xcd;    // DN_TUNE_WGRAD_NO_XCD: weight-gradient blocks in plain (tile-fast) order, splits not tied to XCDs
 };
 inline const DnTune& dn_tune() {
@@ -68,6 +69,7 @@ inline const DnTune& dn_tune() {
     v.no_head_fuse = flag("DN_TUNE_NO_HEAD_FUSE");
     if ((e = getenv("DN_TUNE_WGRAD_BLOCKS"))) v.wgrad_blocks = atol(e);
     if ((e = getenv("DN_TUNE_WGRAD_NOSKIP"))) v.wgrad_noskip = atoi(e) == 2 ? 2 : 1;
+    v.wgrad_no_cot32 = flag("DN_TUNE_WGRAD_NO_COT32");
     v.wgrad_no_xcd = flag("DN_TUNE_WGRAD_NO_XCD");
     return v;
   }();

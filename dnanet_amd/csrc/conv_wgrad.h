@@ -52,12 +52,14 @@ __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int KH, int KW, int HT>
+// COT = output channels per block tile: 64 for bf16 (two 32-channel groups share every A fragment), 32 for layers with at
+// most 32 output channels (a 64-wide tile would stage and multiply 32 channels of zeros) and for fp32.
+template <typename T, int KH, int KW, int HT, int COT = WgTraits<T>::CO_T>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
   using TR = WgTraits<T>;
   constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
   constexpr int EPR = RecTraits<T>::EPR;
-  constexpr int CO_T = TR::CO_T, CI_T = wg_ci_tile(TAPS, sizeof(T)), KSTEP = TR::KSTEP;
+  constexpr int CO_T = COT, CI_T = wg_ci_tile(TAPS, sizeof(T)), KSTEP = TR::KSTEP;
   constexpr int NCOG = CO_T / 32, NCIG = CI_T / 32;
   constexpr int CO_PL = CO_T / EPR, CI_PL = CI_T / EPR;     // planes per tile
   constexpr int PLG = 32 / EPR;                             // planes per 32-channel group
@@ -432,9 +434,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   }
 }
 
-template <typename T, int KH, int KW, int HT = 1>
+template <typename T, int KH, int KW, int HT = 1, int COT = WgTraits<T>::CO_T>
 int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_t stream) {
   using TR = WgTraits<T>;
+  (void)sizeof(TR);
   constexpr int TAPS = KH * KW;
   constexpr bool KSPLIT = TAPS < 4;
   constexpr int SW = wg_strip_width<T>(HT);
@@ -443,10 +446,10 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   if ((long)p.dy_pt * p.H * p.W * p.dy_wmul * 32 >= (1L << 31) || (long)p.a_pt * p.H * p.W * 32 >= (1L << 31))
     return dn_set_error(DN_ERR_ARG, "conv_wgrad: one image of an operand exceeds 2 GiB (32-bit buffer offsets)");
   p.nstrips = p.N * p.nth * p.ntw;
-  p.co_pad = (p.co_pad + TR::CO_T - 1) / TR::CO_T * TR::CO_T;
+  p.co_pad = (p.co_pad + COT - 1) / COT * COT;
   constexpr int CI_T = wg_ci_tile(TAPS, sizeof(T));
   p.ci_pad = (p.ci_pad + CI_T - 1) / CI_T * CI_T;
-  const long tiles = (long)(p.co_pad / TR::CO_T) * (p.ci_pad / CI_T);
+  const long tiles = (long)(p.co_pad / COT) * (p.ci_pad / CI_T);
   const long per_slab = (long)TAPS * p.co_pad * p.ci_pad * 4 * (KSPLIT ? 4 : 1);
   const long target = dn_tune().wgrad_blocks > 0 ? dn_tune().wgrad_blocks : 512;   // two resident workgroups per CU
   long nsplit = std::max<long>(1, (target + tiles - 1) / tiles);
@@ -468,7 +471,7 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   p.xcd_split = xcd ? 1 : 0;
   *nslab_out = (int)nsplit * (KSPLIT ? 4 : 1);
   const long grid = p.xcd_split ? tiles * ((nsplit + 7) / 8 * 8) : tiles * nsplit;
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, HT>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, HT, COT>), dim3((unsigned)grid), dim3(256), 0, stream, p);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

@@ -107,7 +107,8 @@ int dn_conv2d_wgrad(dn_tensor dy, dn_tensor a, float* dw, void* workspace, long 
   DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && cin > 0, "dn_conv2d_wgrad: bad shape");
   DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d_wgrad: bad dtype %d", dtype);
   const int epr = dtype == DN_BF16 ? 16 : 8;
-  const int co_t = dtype == DN_BF16 ? 64 : 32;
+  // output-channel tile: 64 for bf16, 32 for fp32 and for bf16 3x5 layers with at most 32 output channels (wgrad_inst_bf16_k35.hip)
+  const int co_t = dtype == DN_BF16 && !(kh == 3 && kw == 5 && dy.channels <= 32 && !dn_tune().wgrad_no_cot32) ? 64 : 32;
   WgradParams p{};
   p.dy = dy.base; p.dy_pt = dy.planes_total; p.dy_p0 = dy.plane0; p.dy_nplanes = dn_planes(dy.channels, dtype);
   p.dy_gplanes = 1 << 30; p.dy_wmul = 1;
