@@ -14,7 +14,7 @@ int dn_set_error(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt)
 #define WID 4096
 #endif
 int main() {
-  const int N = 256, H = 5, W = WID;
+  const int N = 256, H = CM_H, W = WID;
   const long xrecs = (long)N * (CIN / 16) * H * W, yrecs = (long)N * (COUT / 16) * H * W;
   void *x, *y, *w; float* b;
   hipMalloc(&x, xrecs * 32); hipMalloc(&y, yrecs * 32); hipMalloc(&w, (long)(CIN / 16) * 15 * COUT * 32); hipMalloc(&b, COUT * 4);
@@ -27,7 +27,7 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
-    for (int i = 0; i < 5; ++i) conv_igemm_launch<__bf16, 3, 5, 5, (COUT % 64 == 0 ? 64 : 32)>(p, 0);
+    for (int i = 0; i < 5; ++i) conv_igemm_launch<__bf16, 3, 5, CM_HT, (COUT % 64 == 0 ? 64 : 32)>(p, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     if (rep) printf("%s %d->%d W=%d: %.1f us  %.1f TF/s  %.0f GB/s\n", VARIANT, CIN, COUT, W, ms * 1e3,
