@@ -59,8 +59,9 @@ static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t
     if (dtype != DN_BF16) return dn_set_error(DN_ERR_ARG, "split output needs bf16 storage");
     if (v.wave8) return conv_igemm8_run_bf16_split(p, ht, s);
     if (kh == 3 && kw == 5) return conv_igemm_run_bf16_k35_split(p, ht, cot, s);
+    if (kh == 1 && kw == 3) return conv_igemm_run_bf16_k13_split(p, ht, cot, s);
     if (kh == 1 && kw == 1) return conv_igemm_run_bf16_k11_split(p, ht, cot, s);
-    return dn_set_error(DN_ERR_UNSUPPORTED, "split output: kernel size (%d,%d) is not built (have (3,5), (1,1))", kh, kw);
+    return dn_set_error(DN_ERR_UNSUPPORTED, "split output: kernel size (%d,%d) is not built (have (3,5), (1,3), (1,1))", kh, kw);
   }
   if (v.wave8) return dtype == DN_BF16 ? conv_igemm8_run_bf16(p, ht, s) : conv_igemm8_run_f32(p, ht, s);
   if (dtype == DN_BF16) {
@@ -228,7 +229,7 @@ int dn_conv2d_x3(dn_tensor_x3 x, const void* packed_w, const float* bias, dn_ten
                  int W, int kh, int kw, int relu, void* stream) {
   DN_CHECK_ARG(packed_w, "dn_conv2d_x3: null pointer");
   DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && x.channels > 0 && y.channels > 0, "dn_conv2d_x3: bad shape N=%d H=%d W=%d", N, H, W);
-  DN_CHECK_ARG(kh == 3 && kw == 5, "dn_conv2d_x3: kernel size (%d,%d) is not built (have (3,5))", kh, kw);
+  DN_CHECK_ARG((kh == 3 && kw == 5) || (kh == 1 && kw == 3), "dn_conv2d_x3: kernel size (%d,%d) is not built (have (3,5), (1,3))", kh, kw);
   ConvParams p{};
   if (int rc = x3_input(p, x, "dn_conv2d_x3")) return rc;
   if (int rc = x3_output(p, y, "dn_conv2d_x3")) return rc;

@@ -120,7 +120,7 @@ static int launch_ht(const float* x, const float* wf, ConvParams p, hipStream_t 
   if (tiles > 0x7fffffffL || p.cout_pad / 32 > 65535) return dn_set_error(DN_ERR_ARG, "conv_first: grid out of range");
   // persistent blocks: four per CU (256 CUs), each walking every (grid)th tile
   const dim3 grid((unsigned)std::min<long>(tiles, 1024), (unsigned)(p.cout_pad / 32));
-  if constexpr (sizeof(T) == 2 && KH == 3) {
+  if constexpr (sizeof(T) == 2) {
     if (p.y_lo_off) {          // hi + lo split output (bf16x3 inference mode)
       hipLaunchKernelGGL((conv_first_mfma_kernel<T, KH, KW, HT, CONV_EPI_SPLIT>), grid, dim3(256), 0, s, x, wf, p);
       DN_LAUNCH_CHECK();

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const unsigned char* x, in
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(const unsigned char* x, int x_planes_total, int x_plane0, int nplanes,
                                                    const float* __restrict__ w, const float* __restrict__ b,
-                                                   float* logits, float* probs, int N, int H, int W) {
+                                                   float* logits, float* probs, int N, int H, int W, int lo_off) {
+  // lo_off > 0: x is a hi + lo split tensor (bf16x3), its lo part lo_off planes further: both parts enter the dot product
   constexpr int EPR = RecTraits<T>::EPR, PN = Piece<T>::N;
   const long total = (long)N * H * W;
   for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long)gridDim.x * blockDim.x) {
@@ -130,6 +131,11 @@ __global__ __launch_bounds__(256) void head_kernel(const unsigned char* x, int x
         Piece<T>::unpack(*(const uint4*)(src + 16 * pc), f);
 #pragma unroll
         for (int k = 0; k < PN; ++k) acc = fmaf(f[k], w[pl * EPR + pc * PN + k], acc);
+        if (lo_off > 0) {
+          Piece<T>::unpack(*(const uint4*)(src + (long)lo_off * H * W * 32 + 16 * pc), f);
+#pragma unroll
+          for (int k = 0; k < PN; ++k) acc = fmaf(f[k], w[pl * EPR + pc * PN + k], acc);
+        }
       }
     }
     if (logits) logits[pix] = acc;
@@ -271,7 +277,7 @@ int dn_conv_first_x3(const float* x, const float* wf, const float* bias, dn_tens
                      int kw, int relu, void* stream) {
   DN_CHECK_ARG(x && wf && y.base, "dn_conv_first_x3: null pointer");
   DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && cout > 0 && y.channels == cout, "dn_conv_first_x3: bad shape N=%d H=%d W=%d cout=%d", N, H, W, cout);
-  DN_CHECK_ARG(kh == 3 && kw == 5, "dn_conv_first_x3: kernel size (%d,%d) is not built (have (3,5))", kh, kw);
+  DN_CHECK_ARG((kh == 3 && kw == 5) || (kh == 1 && kw == 3), "dn_conv_first_x3: kernel size (%d,%d) is not built (have (3,5), (1,3))", kh, kw);
   const int yp = dn_planes(cout, DN_BF16);
   DN_CHECK_ARG(y.plane0 >= 0 && y.lo_off >= yp && y.plane0 + y.lo_off + yp <= y.planes_total,
                "dn_conv_first_x3: y planes [%d,%d) + lo part at +%d outside buffer of %d", y.plane0, y.plane0 + yp, y.lo_off, y.planes_total);
@@ -310,11 +316,24 @@ int dn_head_1x1(dn_tensor x, const float* w, const float* b, float* logits, floa
   const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 8192);
   if (dtype == DN_BF16)
     hipLaunchKernelGGL(head_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x.base,
-                       x.planes_total, x.plane0, nplanes, w, b, logits, probs, N, H, W);
+                       x.planes_total, x.plane0, nplanes, w, b, logits, probs, N, H, W, 0);
   else if (dtype == DN_F32)
     hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x.base,
-                       x.planes_total, x.plane0, nplanes, w, b, logits, probs, N, H, W);
+                       x.planes_total, x.plane0, nplanes, w, b, logits, probs, N, H, W, 0);
   else return dn_set_error(DN_ERR_ARG, "dn_head_1x1: bad dtype %d", dtype);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
+}
+
+int dn_head_1x1_x3(dn_tensor_x3 x, const float* w, const float* b, float* logits, float* probs, int N, int H, int W, void* stream) {
+  DN_CHECK_ARG(x.base && w && b && (logits || probs), "dn_head_1x1_x3: null pointer");
+  const int nplanes = dn_planes(x.channels, DN_BF16);
+  DN_CHECK_ARG(x.plane0 >= 0 && (x.lo_off == 0 || x.lo_off >= nplanes) && x.plane0 + x.lo_off + nplanes <= x.planes_total,
+               "dn_head_1x1_x3: planes outside buffer");
+  const long total = (long)N * H * W;
+  const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(head_kernel<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x.base,
+                     x.planes_total, x.plane0, nplanes, w, b, logits, probs, N, H, W, x.lo_off);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }

@@ -8,6 +8,7 @@ int conv_igemm_run_bf16_k35(const ConvParams& p, int ht, int cot, hipStream_t s)
 int conv_igemm_run_bf16_k13(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_bf16_k11(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_bf16_k35_split(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_bf16_k13_split(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_bf16_k11_split(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k35(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k13(const ConvParams& p, int ht, int cot, hipStream_t s);

@@ -101,6 +101,7 @@ _SIGS = {
     "dn_conv2d_x3": (c_int, [DnTensorX3, _P, _P, DnTensorX3, POINTER(DnTensorX3)] + [c_int] * 6 + [_P]),
     "dn_conv2d_head_x3": (c_int, [DnTensorX3, _P, _P, c_int, _P, _P, _P, _P] + [c_int] * 6 + [_P]),
     "dn_conv_first_x3": (c_int, [_P, _P, _P, DnTensorX3] + [c_int] * 7 + [_P]),
+    "dn_head_1x1_x3": (c_int, [DnTensorX3, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "dn_conv_transpose_1x2_x3": (c_int, [DnTensorX3, _P, _P, DnTensorX3, c_int, c_int, c_int, _P]),
     "dn_call_alleles": (c_int, [_P, _P, _P, c_long, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
 }

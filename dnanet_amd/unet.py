@@ -62,8 +62,8 @@ class HipUNet(ParameterTree):
             raise ValueError("num_filters must be a multiple of 8 for the MI355X kernels")
         self.dtype = parse_dtype(dtype)
         self.split_levels = parse_split_levels(dtype, depth)       # > 0: the bf16x3 inference mode on that many levels
-        if self.split_levels and tuple(kernel_size) != (3, 5):
-            raise ValueError("dtype bf16x3 is built for kernel_size (3, 5) only")
+        if self.split_levels and tuple(kernel_size) not in ((3, 5), (1, 3)):
+            raise ValueError("dtype bf16x3 is built for kernel_size (3, 5) and (1, 3)")
         self._eval_cache = None
         self._eval_cache_version = None
         self.profile = None     # set to a list to collect (kernel tag, flops, start event, end event) per conv launch
@@ -354,10 +354,8 @@ class HipUNet(ParameterTree):
             cpad2 = 2 * self._cpad_planes(c[l])
             conv(pre + ".0", l, r3(cat[l], l, cpad2, 0, 2 * P[l]), cat[l].ref(cpad2, 0), r3(tmp, l, c[l], 0, P[l]), tmp.ref(c[l]))
             last = units[pre + ".3"]
-            if l == 0:
+            if l == 0 and hip.lib.dn_conv2d_head_supported(last.cin, last.cout, n, h, w, kh, kw, dt):
                 entry = cache[pre + ".3"]
-                if not hip.lib.dn_conv2d_head_supported(last.cin, last.cout, n, h, w, kh, kw, dt):
-                    raise hip.HipError(f"bf16x3: no fused-head kernel for {last.cout} output channels at N={n}, H={h}, W={w}")
                 if self.profile is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -372,6 +370,9 @@ class HipUNet(ParameterTree):
             out = act(l, l)
             conv(pre + ".3", l, r3(tmp, l, c[l], 0, P[l]), tmp.ref(c[l]), r3(out, l, c[l], 0, P[l]), out.ref(c[l]))
             cur = out
+        # shapes whose last convolution has no single-tile (fused-head) kernel: the head reads the split tensor
+        hip.check(hip.lib.dn_head_1x1_x3(r3(cur, 0, c[0], 0, P[0]), hip.ptr(cache["head_w"]), hip.ptr(cache["head_b"]),
+                                         hip.ptr(logits), hip.ptr(probs), n, h, w, stream))
 
     def _check_input(self, x: torch.Tensor):
         self._require_gpu(x)

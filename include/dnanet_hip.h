@@ -137,6 +137,8 @@ int dn_conv_first_x3(const float* x, const float* wf, const float* bias, dn_tens
                      int kw, int relu, void* stream);
 int dn_conv_transpose_1x2_x3(dn_tensor_x3 x, const void* packed_w, const float* bias2, dn_tensor_x3 y, int N, int H, int Win,
                              void* stream);
+/* dn_head_1x1 on a split tensor (shapes whose last convolution has no fused-head tile) */
+int dn_head_1x1_x3(dn_tensor_x3 x, const float* w, const float* b, float* logits, float* probs, int N, int H, int W, void* stream);
 
 /* nn.MaxPool2d((1,2)) (unet_architecture.py:37): y[n,c,h,w] = max(x[n,c,h,2w], x[n,c,h,2w+1]). */
 int dn_maxpool_1x2(dn_tensor x, dn_tensor y, int N, int H, int Wout, int dtype, void* stream);

@@ -120,12 +120,13 @@ def test_conv_first_x3_vs_torch(gpu_device):
 
 
 @pytest.mark.parametrize("dtype", ["bf16x3", "bf16x3@2", "bf16x3@1"])
-@pytest.mark.parametrize("depth,filters,h,w,n", [(4, 32, 5, 4096, 4), (2, 8, 6, 256, 3), (3, 16, 5, 512, 18)])
-def test_net_logits_vs_oracle(gpu_device, dtype, depth, filters, h, w, n):
+@pytest.mark.parametrize("depth,filters,h,w,n,kernel", [(4, 32, 5, 4096, 4, (3, 5)), (2, 8, 6, 256, 3, (3, 5)), (3, 16, 5, 512, 18, (3, 5)),
+                                                        (4, 8, 5, 256, 2, (1, 3)), (3, 64, 6, 128, 5, (1, 3))])
+def test_net_logits_vs_oracle(gpu_device, dtype, depth, filters, h, w, n, kernel):
     from oracle import unet_oracle as O
     from dnanet_amd.synthetic import make_batch
     from dnanet_amd.unet import HipUNet
-    sd = O.init_state_dict(depth, (3, 5), filters, seed=5)
+    sd = O.init_state_dict(depth, kernel, filters, seed=5)
     g = torch.Generator().manual_seed(1)
     for k, v in sd.items():                      # BatchNorm statistics away from the initial (0, 1)
         if k.endswith("running_mean"): v.copy_(torch.randn(v.shape, generator=g) * 0.2)
@@ -133,7 +134,7 @@ def test_net_logits_vs_oracle(gpu_device, dtype, depth, filters, h, w, n):
     x = torch.from_numpy(make_batch(n, h, w, seed=11, unique=n)[0])
     with torch.no_grad():
         want = O.unet_forward(sd, x, train=False)
-    m = HipUNet(depth, (3, 5), filters, gpu_device, dtype=dtype)
+    m = HipUNet(depth, kernel, filters, gpu_device, dtype=dtype)
     m.load_state_dict(sd)
     m.eval()
     logits, probs = m.infer(x.to(gpu_device))
