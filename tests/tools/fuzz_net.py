@@ -1,4 +1,4 @@
-"""One-off: whole-net inference + one training step against the oracle on random small configurations (fp32 mode)."""
+"""One-off: whole-net inference + one training step against the oracle on random small configurations (fp32 and bf16 modes; inference also in the bf16x3 modes)."""
 import os, sys, random; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from collections import OrderedDict
 import torch
@@ -38,6 +38,11 @@ for case in range(ncase):
             got = m.state_dict()
             for kk in ref_sd:
                 if 'running' in kk and not torch.allclose(got[kk].cpu(), ref_sd[kk], rtol=1e-4, atol=1e-4): msgs.append(f'{kk} running stat')
+    for dtype in ('bf16x3', f'bf16x3@{rng.randint(1, depth + 1)}'):       # inference-only split modes
+        m = HipUNet(depth, k, f, dev, dtype=dtype); m.load_state_dict(sd); m.eval()
+        lg, pr = m.infer(x.to(dev))
+        e = float((lg.cpu() - ref_eval).abs().max() / (ref_eval.abs().max() + 1e-20))
+        if not e < (1e-4 if m.split_levels == depth + 1 else 6e-2): msgs.append(f'{dtype} eval logits {e:.2e}')
     if msgs:
         bad += 1
         print('CASE', dict(depth=depth, k=k, f=f, n=n, h=h, w=w), msgs[:4])
