@@ -118,6 +118,46 @@ def test_fit_loop_matches_oracle_loop(gpu_device):
             assert float(d.max()) <= 2.5 * 1e-3 * 4 and float((d > 2e-4 + 2e-3 * v.abs()).float().mean()) < 1e-2, k
 
 
+def test_the_reference_smoke_test_against_the_oracle_loop(gpu_device):
+    """The reference's one hot-path test (``tests/models/segmentation/test_unet.py:12-19``): ``DNANet_UNet(4, (1, 3))`` with its
+    default 64 filters, ``fit(batch_size=1, num_epochs=5)`` on the two real RD profiles, then ``predict_batch`` -- there a smoke
+    test without numeric assertions, here the same calls checked against the oracle running the reference's loop."""
+    from oracle import unet_oracle as O
+    from dnanet_amd.model import DNANet_UNet
+    g = load_golden("g_real_d4_k35_f8")
+    x, t = g["x"], g["t"]
+    images = _images(x, t)
+    sd0 = O.init_state_dict(4, (1, 3), 64, seed=9)
+    model = DNANet_UNet(4, (1, 3), device="cuda", apply_allele_caller=False)
+    assert model._model.num_filters == 64
+    model._model.load_state_dict(sd0)
+    model.fit(images, batch_size=1, num_epochs=5)                     # fit's defaults: lr 0.005, weight decay 5e-4, no scheduler
+    sd = OrderedDict((k, v.clone()) for k, v in sd0.items())
+    state = O.AdamState(O.trainable_keys(sd), sd)
+    losses = []
+    for epoch in range(5):
+        for s in range(2):
+            loss, _, _ = O.train_step(sd, torch.from_numpy(x[s:s + 1]), torch.from_numpy(t[s:s + 1]), state, 0.005, 5e-4)
+            losses.append(loss)
+    got = model._model.state_dict()
+    assert int(got["bottleneck.double_conv.1.num_batches_tracked"]) == 10
+    # ten Adam steps at lr 5e-3 from the same start: parameters move by up to 5e-2; trajectories agree to a fraction of that
+    moved = max(float((sd[k] - sd0[k]).abs().max()) for k in sd if sd[k].dtype != torch.int64)
+    worst = max(float((got[k].cpu() - sd[k]).abs().max()) for k in sd if sd[k].dtype != torch.int64 and "running" not in k)
+    assert moved > 1e-2 and worst < 0.1 * moved, (moved, worst)
+    preds = model.predict_batch(images)
+    ref = torch.sigmoid(O.unet_forward(sd, torch.from_numpy(x), train=False)).numpy()
+    for i, p in enumerate(preds):
+        # ten aggressive steps on single-profile batches amplify fp32 round-off at the sharp peaks: typical pixels agree
+        assert p.image.shape == (5, 4096, 1)
+        assert np.median(np.abs(p.image - np.transpose(ref[i], (1, 2, 0)))) < 2e-2
+    assert losses[-1] < losses[0]
+    # the prediction path itself, on the oracle's end state: exact to fp32 round-off
+    model._model.load_state_dict(sd)
+    for i, p in enumerate(model.predict_batch(images)):
+        assert np.abs(p.image - np.transpose(ref[i], (1, 2, 0))).max() < 1e-4
+
+
 def test_fit_learns_and_checkpoints(gpu_device, tmp_path):
     from dnanet_amd.model import DNANet_UNet
     from dnanet_amd.synthetic import make_batch
