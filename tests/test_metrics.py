@@ -54,3 +54,78 @@ def test_iou_counts_empty_images():
     full = _image(np.ones((2, 4, 1)))
     preds = [Prediction(image=np.zeros((2, 4, 1))), Prediction(image=np.ones((2, 4, 1)))]
     assert average_binary_iou([empty, full], preds) == 0.5    # empty union adds 0 but is counted
+
+
+# ---- allele-level metrics --------------------------------------------------------------------------------------------
+def _pair(annotated, called, manual=False):
+    from dnanet_amd.data import ArrayImage
+    from dnanet_amd.prediction import Prediction
+    meta = {"called_alleles": annotated}
+    if manual:
+        meta["called_alleles_manual"] = annotated
+    return ArrayImage(data=None, meta=meta), Prediction(image=None, meta={"called_alleles": called})
+
+
+def test_allele_metrics_known_answers_of_the_reference_test():
+    """tests/evaluation/segmentation/test_allele_metrics.py:31-48 of the reference: two annotated markers with two alleles each,
+    the prediction holds the first marker only -> tp 2, fn 2, fp 0."""
+    from dnanet_amd.data import Allele, Marker
+    from dnanet_amd.metrics import allele_f1_score, allele_precision, allele_recall
+    m1 = Marker(name="AMEL", dye_row=0, alleles=[Allele("13"), Allele("15.1")])
+    m2 = Marker(name="Penta E", dye_row=0, alleles=[Allele("14"), Allele("15.1")])
+    image, prediction = _pair([m1, m2], [m1])
+    assert allele_precision([image], [prediction]) == 1.0
+    assert allele_recall([image], [prediction]) == 0.5
+    assert allele_f1_score([image], [prediction]) == 2 * (1.0 * 0.5) / 1.5
+    # nothing called, nothing annotated: 0, not a division error
+    empty_i, empty_p = _pair([], [])
+    assert allele_precision([empty_i], [empty_p]) == 0 and allele_recall([empty_i], [empty_p]) == 0
+    assert allele_f1_score([empty_i], [empty_p]) == 0
+
+
+def test_allele_metric_thresholds_and_errors():
+    """The per-locus RFU filters (DNAnet/evaluation/utils.py:10-126 restated).  No fixture or test of the reference covers them
+    and its module cannot be imported here without a missing third-party package: hand-derived answers, parity unpinned."""
+    from dnanet_amd.data import Allele, Marker
+    from dnanet_amd.metrics import (THRESHOLDS_PER_LOCUS, allele_precision, allele_recall, locus_allele_names,
+                                    min_rfu_per_locus)
+    assert len(THRESHOLDS_PER_LOCUS) == 27 and THRESHOLDS_PER_LOCUS["D18S51"] == {"low": 50, "high": 140}
+    assert min_rfu_per_locus("TH01", "high") == {"TH01": 85} and min_rfu_per_locus("TH01", None, 30) == {"TH01": 30}
+    assert min_rfu_per_locus(None, "between")["SE33"] == {"low": 80, "high": 135}
+    with pytest.raises(ValueError):
+        min_rfu_per_locus("NOPE")
+    with pytest.raises(ValueError):
+        min_rfu_per_locus(None, "medium")
+    called = [Marker(name="TH01", dye_row=1, alleles=[Allele("6", height=40), Allele("7", height=60), Allele("9.3", height=85),
+                                                      Allele("10", height=3000)]),
+              Marker(name="FGA", dye_row=3, alleles=[Allele("20", height=41), Allele("21", height=500)])]
+    assert locus_allele_names(called) == {"TH01_6", "TH01_7", "TH01_9.3", "TH01_10", "FGA_20", "FGA_21"}
+    assert locus_allele_names(called, low_or_high="low") == {"TH01_7", "TH01_9.3", "TH01_10", "FGA_20", "FGA_21"}       # >= 45 / >= 40
+    assert locus_allele_names(called, low_or_high="high") == {"TH01_9.3", "TH01_10", "FGA_21"}                         # >= 85 / >= 95
+    assert locus_allele_names(called, low_or_high="between") == {"TH01_7", "FGA_20"}                                   # strictly inside
+    assert locus_allele_names(called, locus="FGA", min_rfu=100) == {"FGA_21"}
+    as_dicts = [{"name": "TH01", "alleles": [{"name": "6", "height": 40}]}]
+    assert locus_allele_names(as_dicts) == {"TH01_6"}
+    with pytest.raises(ValueError):                      # a threshold but no height
+        locus_allele_names([Marker(name="TH01", dye_row=1, alleles=[Allele("6")])], min_rfu=10)
+    with pytest.raises(ValueError):                      # the same allele twice
+        locus_allele_names([Marker(name="TH01", dye_row=1, alleles=[Allele("6"), Allele("6")])])
+    # donor alleles (no heights) are never filtered; the predictions are
+    donors = [Marker(name="TH01", dye_row=1, alleles=[Allele("7"), Allele("10")])]
+    image, prediction = _pair(donors, called, manual=True)
+    assert allele_recall([image], [prediction], low_or_high_threshold="high") == 0.5          # of {7, 10} only 10 is called >= 85
+    assert allele_precision([image], [prediction], low_or_high_threshold="high") == 1 / 3
+    # analyst annotations with heights are filtered like the predictions
+    analyst = [Marker(name="TH01", dye_row=1, alleles=[Allele("7", height=61), Allele("10", height=2990)])]
+    image, prediction = _pair(analyst, called)
+    assert allele_recall([image], [prediction], low_or_high_threshold="between") == 1.0       # {7} vs {7, FGA_20}
+    assert allele_precision([image], [prediction], low_or_high_threshold="between") == 0.5
+
+
+def test_evaluation_config_with_allele_metrics():
+    import os
+    from conftest import ROOT
+    from dnanet_amd.config_io import load_evaluation_config
+    metrics = load_evaluation_config(os.path.join(ROOT, "config", "evaluation", "segmentation_alleles.yaml"))
+    assert len(metrics) == 13 and "allele_recall_low_or_high_threshold_between" in metrics
+    assert metrics["allele_precision_low_or_high_threshold_high"].keywords == {"low_or_high_threshold": "high"}
