@@ -129,3 +129,38 @@ def test_evaluation_config_with_allele_metrics():
     metrics = load_evaluation_config(os.path.join(ROOT, "config", "evaluation", "segmentation_alleles.yaml"))
     assert len(metrics) == 13 and "allele_recall_low_or_high_threshold_between" in metrics
     assert metrics["allele_precision_low_or_high_threshold_high"].keywords == {"low_or_high_threshold": "high"}
+
+
+def test_allele_metrics_on_the_real_profiles_through_the_caller():
+    """The reference's known-answer set-up (tests/test_allele_callers.py:7-61) carried through to the metrics: the analyst's
+    annotation mask of a real profile fed as the "prediction" reproduces the annotated alleles, so every allele metric of the
+    reference's evaluation config is 1 (or 0 where the RFU band holds no allele at all); dropping a dye row lowers recall only."""
+    from conftest import GOLDEN_DIR, ROOT
+    from dnanet_amd.allele_caller import NearestBasePairCaller
+    from dnanet_amd.cli import write_metrics
+    from dnanet_amd.config_io import load_evaluation_config
+    from dnanet_amd.data import Panel
+    panel = Panel(os.path.join(GOLDEN_DIR, "panel.xml"))
+    caller, scaler = NearestBasePairCaller(), np.linspace(65, 475, 4096)
+    images, exact, partial = [], [], []
+    for stem in ("1A2_A01_01", "1A2_E01_13"):
+        z = np.load(os.path.join(GOLDEN_DIR, f"allele_inputs_{stem}.npz"))
+        rfu, mask = z["rfu"], z["mask"].astype(np.float32)
+        truth = caller.translate_pixels_to_alleles(scaler[None], mask, rfu, panel)
+        image = ArrayImage(data=rfu, annotation=Annotation(image=mask.astype(np.int8)), meta={"called_alleles": truth},
+                           _scaler=scaler, _panel=panel)
+        images.append(image)
+        exact.append(caller.call_alleles(image, Prediction(image=mask, meta={})))
+        cut = mask.copy()
+        cut[0] = 0                                            # nothing predicted on the first dye row
+        partial.append(caller.call_alleles(image, Prediction(image=cut, meta={})))
+    metrics = load_evaluation_config(os.path.join(ROOT, "config", "evaluation", "segmentation_alleles.yaml"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        full = write_metrics(metrics, images, exact, os.path.join(d, "m.txt"))
+        part = write_metrics(metrics, images, partial, os.path.join(d, "p.txt"))
+    allele = {k: v for k, v in full.items() if k.startswith("allele")}
+    assert len(allele) == 9 and all(v in (0.0, 1.0) for v in allele.values()) and allele["allele_f1_score"] == 1.0
+    assert allele["allele_precision"] == allele["allele_recall"] == 1.0
+    assert part["allele_precision"] == 1.0 and 0.5 < part["allele_recall"] < 1.0
+    assert full["pixel_f1_score"] == 1.0 and part["pixel_recall"] < 1.0
