@@ -19,9 +19,9 @@ from functools import partial
 from .caching import ArrowCacheDataset
 from .data import ArrayDataset, NpyDirDataset, SyntheticDataset
 from .metrics import METRICS
-from .model import DNANet_UNet, Model
+from .model import DNANet_UNet, HumanAnalysis, Model
 
-MODELS = {"model": {"unet": DNANet_UNet}}
+MODELS = {"model": {"unet": DNANet_UNet, "human_analysis": HumanAnalysis}}      # config_io.py:29
 # The reference registers its .hid reader here (``config_io.py:28``); parsing .hid files is outside the hot path, so
 # the datasets of this build are array-backed.  A reference ``HIDDataset`` can be passed to the model API directly.
 DATASETS = {"dataset": {"npy": NpyDirDataset, "synthetic": SyntheticDataset, "arrow_cache": ArrowCacheDataset}}

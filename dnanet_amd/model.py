@@ -67,6 +67,27 @@ class Model(ABC):
         raise NotImplementedError
 
 
+class HumanAnalysis(Model):
+    """The analyst as a "model" (``DNAnet/models/segmentation/human_analysis.py:13-37``, registry name ``human_analysis``):
+    the manual annotations stored under ``called_alleles_manual`` in an image's meta come back as the called alleles, without
+    the sex / Y markers the donor ground truth does not list, so that the allele metrics score analysts like a network."""
+
+    def predict(self, image) -> Prediction:
+        manual = image.meta.get("called_alleles_manual")
+        if manual is None:
+            raise ValueError("No `called_alleles_manual` found when running HumanAnalysis model, set "
+                             "`ground_truth_as_annotations=True` in the data config file to load `called_alleles_manual`.")
+        from .allele_caller import NON_AUTOSOMAL_MARKERS
+        kept = [marker for marker in manual if marker.name not in NON_AUTOSOMAL_MARKERS]
+        return Prediction(image=None, meta={"called_alleles": kept, "original_image_path": image.path})
+
+    def save(self, model_dir):       # nothing to store
+        pass
+
+    def load(self, model_dir):
+        pass
+
+
 class TrainableModel(Model, ABC):
     @abstractmethod
     def fit(self, dataset, **kwargs):

@@ -164,3 +164,22 @@ def test_allele_metrics_on_the_real_profiles_through_the_caller():
     assert allele["allele_precision"] == allele["allele_recall"] == 1.0
     assert part["allele_precision"] == 1.0 and 0.5 < part["allele_recall"] < 1.0
     assert full["pixel_f1_score"] == 1.0 and part["pixel_recall"] < 1.0
+
+
+def test_human_analysis_model_scores_like_a_network():
+    """``-m human_analysis``: the analyst's alleles as predictions (minus AMEL / DYS markers) against donor alleles."""
+    from conftest import ROOT
+    from dnanet_amd.config_io import load_model
+    from dnanet_amd.data import Allele, Marker
+    from dnanet_amd.metrics import allele_precision, allele_recall
+    model = load_model(os.path.join(ROOT, "config", "models", "human_analysis.yaml"))
+    donors = [Marker(name="TH01", dye_row=1, alleles=[Allele("7"), Allele("10")]), Marker(name="FGA", dye_row=3, alleles=[Allele("21")])]
+    manual = [Marker(name="TH01", dye_row=1, alleles=[Allele("7", height=300), Allele("9.3", height=90)]),
+              Marker(name="AMEL", dye_row=0, alleles=[Allele("X", height=900)])]
+    image = ArrayImage(data=None, path="a.hid", meta={"called_alleles": donors, "called_alleles_manual": manual})
+    (pred,) = model.predict_batch([image])
+    assert pred.image is None and pred.meta["original_image_path"] == "a.hid"
+    assert [m.name for m in pred.meta["called_alleles"]] == ["TH01"]
+    assert allele_precision([image], [pred]) == 0.5 and allele_recall([image], [pred]) == 1 / 3
+    with pytest.raises(ValueError):
+        model.predict(ArrayImage(data=None, meta={}))
