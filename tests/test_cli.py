@@ -23,6 +23,12 @@ def test_split_is_seeded_and_partitions():
     assert len(a) == 15 and len(b) == 5 and sorted(list(a) + list(b)) == list(range(20))
     with pytest.raises(ValueError):
         ds.split(1.0)
+    # the known answer of the reference's own test (tests/data/data_models/test_base.py:15-30): 20 images, fraction 0.8, seed 42
+    # -> images 4, 14, 5, 19 form the second part, in that order; `-rs 42` reproduces the reference's partitions
+    d1, d2 = ArrayDataset([f"dummy_path_{i}" for i in range(20)]).split(fraction=0.8, seed=42)
+    assert len(d1) == 16 and list(d2) == ["dummy_path_4", "dummy_path_14", "dummy_path_5", "dummy_path_19"]
+    d1, d2 = ArrayDataset([f"dummy_path_{i}" for i in range(1, 20)]).split(fraction=0.78)
+    assert (len(d1), len(d2)) == (14, 5)
 
 
 def test_k_fold_covers_every_image_once_as_test():
