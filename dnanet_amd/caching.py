@@ -99,7 +99,7 @@ class ArrowCacheDataset(ArrayDataset):
     ``caching.py:18-41``) as a dataset for ``fit`` / ``predict_batch``.  ``block_inputs`` / ``block_targets`` are the
     contiguous arrays behind the images."""
 
-    def __init__(self, cache_path, limit: Optional[int] = None, shuffle: bool = False):
+    def __init__(self, cache_path, limit: Optional[int] = None, shuffle: bool = False, group_replicas_in_split: bool = False):
         cache_path = str(cache_path)
         if not os.path.isdir(cache_path):
             raise FileNotFoundError(f"Cache directory {cache_path} does not exist.")
@@ -126,7 +126,7 @@ class ArrowCacheDataset(ArrayDataset):
             meta = {"called_alleles": markers_from_json(row["called_alleles"]), "noc": noc_from_rd_file_name(row["hid_paths"])}
             images.append(ArrayImage(data=self.block_inputs[i], annotation=Annotation(image=self.block_targets[i]),
                                      path=row["hid_paths"], meta=meta, _scaler=np.array(row["scalers"]), _panel=panels[key]))
-        super().__init__(images, shuffle)
+        super().__init__(images, shuffle, group_replicas_in_split)
 
 
 def write_cache(cache_path, images: Sequence) -> None:

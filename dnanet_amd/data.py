@@ -11,6 +11,7 @@ from __future__ import annotations
 import glob
 import os
 import random
+import re
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
 from itertools import islice
@@ -138,9 +139,13 @@ class ArrayDataset(Sequence):
     ``int(len * fraction)``; ``split_k_fold(k, seed)`` deals the shuffled images into k folds whose sizes differ by at
     most one and returns (train, test) pairs, fold i being the test set of pair i."""
 
-    def __init__(self, data: Sequence = (), shuffle: bool = False):
+    def __init__(self, data: Sequence = (), shuffle: bool = False, group_replicas_in_split: bool = False):
         self._data = list(data)
         self.shuffle = shuffle
+        # the `group_replicas_in_split` key of the reference's data configs (``config/data/dnanet_rd.yaml``,
+        # ``hid_dataset.py:344-412``): replicas of one mixture (file names sharing the prefix "1A2") stay on one side of a
+        # split and every number of contributors (the prefix's last digit) is divided in the same proportion
+        self.group_replicas_in_split = group_replicas_in_split
 
     def __len__(self) -> int:
         return len(self._data)
@@ -158,6 +163,8 @@ class ArrayDataset(Sequence):
     def split(self, fraction: float, seed: Optional[float] = None) -> Tuple["ArrayDataset", "ArrayDataset"]:
         if not 0 < fraction < 1:
             raise ValueError(f"Fraction should be between 0 and 1, got {fraction}.")
+        if self.group_replicas_in_split:
+            return self._split_grouped(fraction, seed)
         random.seed(shared_seed(seed))
         order = random.sample(self._data, len(self._data))
         cut = int(len(order) * fraction)
@@ -166,13 +173,18 @@ class ArrayDataset(Sequence):
     def split_k_fold(self, n_folds: int, seed: Optional[float] = None) -> List[Tuple["ArrayDataset", "ArrayDataset"]]:
         if n_folds < 2 or n_folds > len(self._data):
             raise ValueError(f"Cannot make {n_folds} folds out of {len(self._data)} images.")
-        random.seed(shared_seed(seed))
-        order = random.sample(self._data, len(self._data))
-        base, extra = divmod(len(order), n_folds)
-        folds = [order[i * base:(i + 1) * base] for i in range(n_folds)]
-        for k, item in enumerate(order[n_folds * base:]):      # the remainder goes one each to the first folds
-            folds[k % n_folds].append(item)
-        assert extra == len(order) - n_folds * base
+        seed = shared_seed(seed)
+        if self.group_replicas_in_split:
+            # per number of contributors: shuffle the mixtures, deal them into k folds, take their replicas along
+            random.seed(seed)
+            folds = [[] for _ in range(n_folds)]
+            for by_prefix in self._replica_groups().values():
+                prefixes = list(by_prefix)
+                random.shuffle(prefixes)
+                for i, part in enumerate(_deal_in_folds(prefixes, n_folds, seed)):
+                    folds[i].extend(im for prefix in part for im in by_prefix[prefix])
+        else:
+            folds = _deal_in_folds(self._data, n_folds, seed)
         for fold in folds:
             random.shuffle(fold)
         pairs = []
@@ -180,6 +192,47 @@ class ArrayDataset(Sequence):
             train = [im for j, fold in enumerate(folds) if j != i for im in fold]
             pairs.append((ArrayDataset(train, self.shuffle), ArrayDataset(folds[i], self.shuffle)))
         return pairs
+
+
+    def _replica_groups(self) -> Dict[str, Dict[str, list]]:
+        """number of contributors -> mixture prefix -> its images, both in order of first appearance (``hid_dataset.py:414-426``)."""
+        groups: Dict[str, Dict[str, list]] = {}
+        for im in self._data:
+            prefix = rd_prefix(os.path.splitext(os.path.basename(str(im.path)))[0])
+            groups.setdefault(prefix[-1], {}).setdefault(prefix, []).append(im)
+        return groups
+
+    def _split_grouped(self, fraction: float, seed) -> Tuple["ArrayDataset", "ArrayDataset"]:
+        random.seed(shared_seed(seed))
+        first, second = [], []
+        for by_prefix in self._replica_groups().values():
+            prefixes = list(by_prefix)
+            cut = int(len(prefixes) * fraction)
+            random.shuffle(prefixes)
+            first.extend(im for prefix in prefixes[:cut] for im in by_prefix[prefix])
+            second.extend(im for prefix in prefixes[cut:] for im in by_prefix[prefix])
+        random.shuffle(first)              # replicas still sit next to each other
+        random.shuffle(second)
+        return ArrayDataset(first, self.shuffle), ArrayDataset(second, self.shuffle)
+
+
+def rd_prefix(stem: str) -> str:
+    """'1A2_A01_01' -> '1A2' (``DNAnet/utils.py:35-47``): data set, mixture letter, number of contributors."""
+    if not re.match(r"\d[ABCDEF]\d", stem[:3]):
+        raise ValueError(f"Cannot take prefix from provided file name: {stem}")
+    return stem.split("_")[0]
+
+
+def _deal_in_folds(items: Sequence, n_folds: int, seed) -> List[list]:
+    """``split_data_in_k_folds`` (``DNAnet/data/split.py:8-40``): (re)seed, shuffle a copy, fold i gets the i-th run of
+    ``len // k`` items, what is left over goes one each to folds 0, 1, ..."""
+    random.seed(seed)
+    order = random.sample(list(items), len(items))
+    base = len(order) // n_folds
+    folds = [order[i * base:(i + 1) * base] for i in range(n_folds)]
+    for k, item in enumerate(order[n_folds * base:]):
+        folds[k % n_folds].append(item)
+    return folds
 
 
 class NpyDirDataset(ArrayDataset):

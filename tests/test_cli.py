@@ -31,6 +31,31 @@ def test_split_is_seeded_and_partitions():
     assert (len(d1), len(d2)) == (14, 5)
 
 
+def test_split_grouped_by_replicas_and_number_of_contributors():
+    """`group_replicas_in_split: true` (the reference's config/data/dnanet_rd.yaml; hid_dataset.py:344-412): the replicas of a
+    mixture never straddle a split, every number of contributors is divided in the same proportion, seeded runs repeat.  (The
+    reference pins its version on a cached dataset whose arrow file is a Git-LFS pointer here: structural checks only.)"""
+    from collections import Counter
+    from dnanet_amd.data import ArrayImage, rd_prefix
+    names = [f"1{letter}{noc}_{well}_{rep:02d}.hid" for noc in (2, 3, 4, 5) for letter in "ABCDE" for rep, well in enumerate(("A01", "B02", "C03"))]
+    ds = ArrayDataset([ArrayImage(data=None, path=n) for n in names], group_replicas_in_split=True)
+    prefix = lambda im: rd_prefix(os.path.basename(im.path)[:-4])
+    a, b = ds.split(0.8, seed=42)
+    assert len(a) + len(b) == 60 and not {prefix(im) for im in a} & {prefix(im) for im in b}
+    assert Counter(prefix(im)[-1] for im in b) == {"2": 3, "3": 3, "4": 3, "5": 3}          # one mixture of five per NoC
+    a2, b2 = ds.split(0.8, seed=42)
+    assert [im.path for im in a] == [im.path for im in a2] and [im.path for im in b] == [im.path for im in b2]
+    assert [im.path for im in ds.split(0.8, seed=43)[1]] != [im.path for im in b]
+    pairs = ds.split_k_fold(5, seed=42)
+    assert sorted(im.path for _, t in pairs for im in t) == sorted(names)
+    for train, test in pairs:
+        assert not {prefix(im) for im in train} & {prefix(im) for im in test}
+        assert Counter(prefix(im)[-1] for im in test) == {"2": 3, "3": 3, "4": 3, "5": 3}
+    with pytest.raises(ValueError):
+        ArrayDataset([ArrayImage(data=None, path="ladder_01.hid")], group_replicas_in_split=True).split(0.5)
+    assert rd_prefix("1A2_A01_01") == "1A2"
+
+
 def test_k_fold_covers_every_image_once_as_test():
     ds = ArrayDataset(list(range(23)))
     pairs = ds.split_k_fold(5, seed=42)
