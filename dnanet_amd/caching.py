@@ -129,6 +129,18 @@ class ArrowCacheDataset(ArrayDataset):
         super().__init__(images, shuffle, group_replicas_in_split)
 
 
+def hid_dataset(root=None, use_cache: bool = False, cache_path=None, limit: Optional[int] = None, shuffle: bool = False,
+                group_replicas_in_split: bool = False, **parsing_options) -> ArrowCacheDataset:
+    """The reference's dataset name ``hid`` (``config/data/dnanet_rd.yaml``, ``hid_dataset.py:30-120``) for the case this build
+    covers: ``use_cache: true`` with a ``cache_path`` written by the reference (or by ``write_cache``).  The keys that steer the
+    ``.hid`` parser (annotations, ladders, thresholds, ...) are accepted and unused -- the cache already holds their result;
+    reading raw ``.hid`` files stays with the reference."""
+    if not (use_cache and cache_path):
+        raise NotImplementedError("dataset `hid`: this build reads the reference's arrow cache (`use_cache: true` + `cache_path`); "
+                                  "parsing raw .hid files is done by the reference (run it once with `cache_path` set to write the cache)")
+    return ArrowCacheDataset(cache_path, limit=limit, shuffle=shuffle, group_replicas_in_split=group_replicas_in_split)
+
+
 def write_cache(cache_path, images: Sequence) -> None:
     """``write_to_hf_cache`` (``caching.py:82-125``): the same columns and feature types, saved with ``datasets``."""
     import datasets

@@ -16,7 +16,7 @@ import yaml
 
 from functools import partial
 
-from .caching import ArrowCacheDataset
+from .caching import ArrowCacheDataset, hid_dataset
 from .data import ArrayDataset, NpyDirDataset, SyntheticDataset
 from .metrics import METRICS
 from .model import DNANet_UNet, HumanAnalysis, Model
@@ -24,7 +24,7 @@ from .model import DNANet_UNet, HumanAnalysis, Model
 MODELS = {"model": {"unet": DNANet_UNet, "human_analysis": HumanAnalysis}}      # config_io.py:29
 # The reference registers its .hid reader here (``config_io.py:28``); parsing .hid files is outside the hot path, so
 # the datasets of this build are array-backed.  A reference ``HIDDataset`` can be passed to the model API directly.
-DATASETS = {"dataset": {"npy": NpyDirDataset, "synthetic": SyntheticDataset, "arrow_cache": ArrowCacheDataset}}
+DATASETS = {"dataset": {"npy": NpyDirDataset, "synthetic": SyntheticDataset, "arrow_cache": ArrowCacheDataset, "hid": hid_dataset}}
 
 
 def get_config_path(name: str, kind: Optional[str] = None, root="." ) -> Path:

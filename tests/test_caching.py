@@ -83,3 +83,29 @@ def test_cached_dataset_loads_through_the_data_config(tmp_path):
     cfg = tmp_path / "cached.yaml"
     cfg.write_text(f"dataset:\n  name: arrow_cache\n  cache_path: {tmp_path / 'c'}\n  limit: 2\n")
     assert len(load_dataset(str(cfg))) == 2
+
+
+def test_reference_data_config_name_hid_reads_the_cache(tmp_path):
+    """The reference's own data config (dataset name `hid`, its parser keys and all) works when it points at a cache:
+    `use_cache: true` + `cache_path`; without a cache the build says that parsing .hid files is the reference's job."""
+    import yaml
+    from conftest import ROOT
+    from dnanet_amd.caching import write_cache
+    from dnanet_amd.config_io import load_dataset
+    from dnanet_amd.data import Panel
+    panel = Panel(os.path.join(GOLDEN_DIR, "panel.xml"))
+    images = _images(8, panel)
+    write_cache(tmp_path / "cache", images)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "data", "dnanet_rd.yaml")))
+    assert cfg["dataset"]["name"] == "hid" and cfg["dataset"]["group_replicas_in_split"] is True
+    cfg["dataset"]["cache_path"] = str(tmp_path / "cache")
+    (tmp_path / "data.yaml").write_text(yaml.safe_dump(cfg))
+    ds = load_dataset(str(tmp_path / "data.yaml"))
+    assert len(ds) == 8 and ds.group_replicas_in_split
+    a, b = ds.split(0.5, seed=1)
+    stem = lambda im: os.path.basename(im.path).split("_")[0]
+    assert len(a) + len(b) == 8 and not {stem(im) for im in a} & {stem(im) for im in b}
+    cfg["dataset"]["use_cache"] = False
+    (tmp_path / "raw.yaml").write_text(yaml.safe_dump(cfg))
+    with pytest.raises(NotImplementedError, match="arrow cache"):
+        load_dataset(str(tmp_path / "raw.yaml"))
