@@ -138,6 +138,10 @@ def hid_dataset(root=None, use_cache: bool = False, cache_path=None, limit: Opti
     if not (use_cache and cache_path):
         raise NotImplementedError("dataset `hid`: this build reads the reference's arrow cache (`use_cache: true` + `cache_path`); "
                                   "parsing raw .hid files is done by the reference (run it once with `cache_path` set to write the cache)")
+    if parsing_options.get("ground_truth_as_annotations"):
+        raise NotImplementedError("dataset `hid`: `ground_truth_as_annotations` replaces the annotated alleles by donor genotypes read from "
+                                  "the reference's resource files (hid_dataset.py:130-136); load such a dataset with the reference and "
+                                  "hand it to the model API")
     return ArrowCacheDataset(cache_path, limit=limit, shuffle=shuffle, group_replicas_in_split=group_replicas_in_split)
 
 
