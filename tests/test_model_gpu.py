@@ -331,7 +331,8 @@ def test_device_pixel_counts_equal_host_metrics(gpu_device):
     preds = model.predict_batch(images)
     assert all(hasattr(p, "_pixel_counts") for p in preds)
     bare = [Prediction(image=p.image, meta=p.meta) for p in preds]
-    for name, fn in M.METRICS.items():
+    pixel_metrics = {k: v for k, v in M.METRICS.items() if not k.startswith("allele")}     # the allele metrics read the caller's output
+    for name, fn in pixel_metrics.items():
         assert fn(images=images, predictions=preds) == fn(images=images, predictions=bare), name
     # the kernel itself on crafted values: 0.5 is positive for ">=" and negative for ">"
     from dnanet_amd import hip
@@ -346,5 +347,5 @@ def test_device_pixel_counts_equal_host_metrics(gpu_device):
     again = model.predict_batch(images)
     assert not hasattr(again[0], "_pixel_counts") and all(hasattr(p, "_pixel_counts") for p in again[1:])
     bare = [Prediction(image=p.image, meta=p.meta) for p in again]
-    for name, fn in M.METRICS.items():
+    for name, fn in pixel_metrics.items():
         assert fn(images=images, predictions=again) == fn(images=images, predictions=bare), name
