@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import json
 import os
-from itertools import islice
 from pathlib import Path
 from typing import List, Optional, Sequence, Tuple
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 import glob
 import os
 from pathlib import Path
-from typing import Any, Iterable, Mapping, MutableMapping, Optional, Union
+from typing import Any, Iterable, Mapping, MutableMapping, Optional
 
 import yaml
 

@@ -18,7 +18,7 @@ import torch
 
 from . import hip
 from .hip import BF16, F32, PlaneBuffer
-from .params import ConvUnit, ParameterTree, UpUnit
+from .params import ConvUnit, ParameterTree
 
 BN_EPS = 1e-5       # nn.BatchNorm2d default used by the reference (unet_architecture.py:17,21)
 BN_MOMENTUM = 0.1
