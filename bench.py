@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl = RCCL over xGMI (the measured configuration); gloo lets the whole "
                          "N > 1 path be rehearsed with several ranks sharing one GPU (collectives staged through the host)")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="initialise the process group even with one rank (exercises the RCCL code path of the N > 1 run on one GPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous rehearsal on the CPU (gloo, stub step, no GPU): what the tests use")
     return ap.parse_args(argv)
@@ -378,7 +380,13 @@ def main():
         sys.exit(2)
     if args.dry_run:
         return dry_run(args, rank, world)
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
+    if distributed and "MASTER_ADDR" not in os.environ:       # one rank without a launcher
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     ndev = torch.cuda.device_count()
     if local_rank >= ndev and args.backend == "nccl":
         print(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible); RCCL needs one device per rank", file=sys.stderr)

@@ -30,3 +30,20 @@ def test_bench_two_ranks_sharing_the_gpu(gpu_device):
     assert 0.0 < tr["loss"] < 1.0
     g = d["train_step_global"]
     assert g["per_gpu_batch"] == 16 and g["global_batch"] == 32 and g["scaling"] == "strong" and 0.0 < g["loss"] < 1.0
+
+
+def test_bench_rccl_code_path_with_one_rank(gpu_device):
+    """`--force-distributed`: the process group (backend nccl = RCCL), device barrier, max-reduce of the timing, the data-parallel
+    trainer with its bucketed all-reduce on a side stream and the strong-scaling leg, all with one rank: every call of the
+    N > 1 run except the other ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-distributed", "--batch", "16",
+                           "--steps", "2", "--warmup", "1", "--global-batch", "32"], capture_output=True, text=True, timeout=170,
+                          env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    d = json.loads([l for l in proc.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl"
+    tr = d["train_step"]
+    assert tr["comm"]["backend"] == "nccl" and tr["comm"]["world_size_seen_by_rank0"] == 1 and tr["comm"]["gradient_buckets_per_step"] >= 2
+    assert "RCCL" in tr["parallelism"] and 0.0 < tr["loss"] < 1.0
+    assert d["train_step_global"]["per_gpu_batch"] == 32 and 0.0 < d["train_step_global"]["loss"] < 1.0
