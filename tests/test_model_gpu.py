@@ -349,3 +349,21 @@ def test_device_pixel_counts_equal_host_metrics(gpu_device):
     bare = [Prediction(image=p.image, meta=p.meta) for p in again]
     for name, fn in pixel_metrics.items():
         assert fn(images=images, predictions=again) == fn(images=images, predictions=bare), name
+
+
+def test_empty_and_short_inputs(gpu_device):
+    """Edge cases of the model API: an empty batch predicts nothing; a dataset shorter than one batch still trains ONE step per
+    epoch on the short batch (``steps_per_epoch = max(1, len // batch_size)``, trainable_unet.py:183-184, with ``chunks`` keeping the
+    remainder); one image is a batch of one."""
+    from dnanet_amd.model import DNANet_UNet
+    from dnanet_amd.synthetic import make_batch
+    x, t = make_batch(3, 5, 256, seed=1, unique=3)
+    images = _images(x, t)
+    model = DNANet_UNet(2, (3, 5), 8, device="cuda", apply_allele_caller=False)
+    assert model.predict_batch([]) == []
+    before = model._model.flat_params.clone()
+    model.fit(images, batch_size=4, num_epochs=2)
+    assert not torch.equal(model._model.flat_params, before)
+    assert int(model._model.state_dict()["bottleneck.double_conv.1.num_batches_tracked"]) == 2
+    one = model.predict(images[0])
+    assert one.image.shape == (5, 256, 1) and np.array_equal(one.image, model.predict_batch(images)[0].image)
