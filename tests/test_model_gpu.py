@@ -367,3 +367,9 @@ def test_empty_and_short_inputs(gpu_device):
     assert int(model._model.state_dict()["bottleneck.double_conv.1.num_batches_tracked"]) == 2
     one = model.predict(images[0])
     assert one.image.shape == (5, 256, 1) and np.array_equal(one.image, model.predict_batch(images)[0].image)
+    # a validation set shorter than a batch: zero validation steps per epoch (len // batch_size, :186-187), training goes on
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.fit(images, batch_size=2, num_epochs=2, validation_set=images[:1])
+    assert int(model._model.state_dict()["bottleneck.double_conv.1.num_batches_tracked"]) >= 4
