@@ -5,19 +5,28 @@
 
 A step = one eval-mode pass of the shipped U-Net (depth 4, kernel (3,5), 32 filters, config/models/unet.yaml) over one
 batch of 256 synthetic 6-dye x 4096-scan electropherograms already resident in HBM (BASELINE.json configs[1]); ``value``
-is that leg in bf16.  With ``--gpus N`` and no WORLD_SIZE in the environment this script starts the N ranks itself
-(``python -m torch.distributed.run`` as a child, before anything touches the GPU); under a launcher it checks that the
-world size equals ``--gpus`` and refuses to run otherwise.  Inference shards by profile, so every rank runs its own
-batch (weak scaling, no data-path collective) and ``value`` is the whole-job profiles/s.
+is that leg in **fp32**, the reference's precision and the mode the GPU tests prove mask- and allele-identical to the
+reference (bf16 differs in a few dozen pixels / alleles -- it is a leg, not the headline).  With ``--gpus N`` and no
+WORLD_SIZE in the environment this script starts the N ranks itself (``python -m torch.distributed.run`` as a child,
+before anything touches the GPU); under a launcher it checks that the world size equals ``--gpus`` and refuses to run
+otherwise.  Inference shards by profile, so every rank runs its own batch (weak scaling, no data-path collective) and
+``value`` is the whole-job profiles/s.
 
 The one JSON line also carries
-  * ``roofline``: the dominant kernel of the headline leg, timed live with HIP events on the launch stream:
-    algorithmic FLOP / launch duration vs the dense MFMA peak of the dtype (MI355X_MICROARCH.md);
-  * ``legs``: the other halves of configs[1] -- the reference's own precision (fp32) on the same batch, and both
-    precisions on the reference's HIDImage shape (5 dyes) -- each with its own roofline;
-  * ``train_step``: fwd + Dice + bwd + Adam profiles/s (bf16, and fp32 under ``train_step_f32``); data parallel over
-    RCCL when N > 1 (configs[3]: 256 profiles per GPU, and the global batch of 2048 split over the ranks);
-  * ``parity``: mask pixels / called alleles that differ between the bf16 and the fp32 kernels on 64 profiles;
+  * ``roofline``: the dominant kernel of the headline leg, timed live with HIP events on the launch stream.  ``frac`` =
+    FLOP of the MFMAs the kernel ISSUES / launch duration / dense MFMA peak of the dtype (MI355X_MICROARCH.md): the
+    3x5 kernels leave out, at compile time, the (kernel row, output row) pairs that only meet the zero rows above /
+    below the image (2 of 3 H), so the PyTorch-convention FLOP count overstates their work; that nominal figure is
+    kept as ``frac_nominal``;
+  * ``legs``: the other halves of configs[1] -- bf16 and the hi + lo split bf16 modes on the same batch, and fp32 /
+    bf16 / bf16x3 on the reference's HIDImage shape (5 dyes) -- each with its own roofline;
+  * ``train_step*``: fwd + Dice + bwd + Adam profiles/s at 256 profiles (fp32, bf16; 6 and 5 dyes), each with the HIP-event
+    time beside the wall time, the caching-allocator deltas over the timed region (the step's buffers are a persistent
+    arena: 0 device allocations) and the roofline of its dominant kernel, the weight gradient (from a profiled,
+    single-stream step after the timed region); data parallel over RCCL when N > 1 (configs[3]);
+  * ``train_step_n16_h5*``: configs[2] -- ``fit()``'s own path (resident set + HIP-graph replay) on 348 synthetic
+    profiles at train.py's batch of 16: 21 steps per epoch, the 12-profile tail dropped;
+  * ``parity``: mask pixels / called alleles that differ between the bf16 modes and the fp32 kernels on 64 profiles;
   * ``cpu_baseline``: the CPU oracle (a torch fp32 port of the reference path) timed on this box's host cores on a
     bounded sample, inference and one training step (rank 0, N=1 only).
 """
@@ -36,9 +45,11 @@ sys.path.insert(0, ROOT)
 
 FWD_FLOP_H5 = 58_531_512_320          # SURVEY 8d, per profile, H=5
 TRAIN_FLOP_H5 = 175_574_876_160       # fwd + dgrad + wgrad per profile, H=5
+CONV35_FLOP_H5 = 57_271_910_400       # the eighteen 3x5 convolutions of the forward pass, first one included
+FIRST_FLOP_H5 = 19_660_800            # encoders.0 conv1 (1 -> 32): taps are the K dimension, nothing is skipped
 BF16_PEAK_TFLOPS = 2500.0             # dense bf16 MFMA peak, MI355X_MICROARCH.md
 F32_PEAK_TFLOPS = 157.3
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def parse_args(argv=None):
@@ -48,8 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="profiles per GPU per step")
     ap.add_argument("--rows", type=int, default=6, help="dye rows (6 = BASELINE.json wording, 5 = reference HIDImage)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3", "bf16x3@2"],
-                    help="precision of the headline leg (bf16x3*: inference-only hi + lo split bf16; the training legs then run in bf16)")
+    ap.add_argument("--dtype", default="fp32", choices=["bf16", "fp32", "bf16x3", "bf16x3@2"],
+                    help="precision of the headline leg; fp32 = the reference's arithmetic and the parity-proven mode "
+                         "(bf16x3*: inference-only hi + lo split bf16; the training legs then run in bf16)")
     # (the bf16x3 inference modes are reported as legs: infer_bf16x3_h6, infer_bf16x3@2_h6, infer_bf16x3_h5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
@@ -153,7 +165,7 @@ def cpu_baseline(rows: int, seconds_budget: float = 24.0):
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU legs
 # ---------------------------------------------------------------------------------------------------------------------
-KERNEL_SOURCES = ("conv_igemm.h", "common.h", "api.hip", "conv_inst_bf16_k35.hip")   # what the dominant kernel is built from
+KERNEL_SOURCES = ("conv_igemm.h", "conv_igemm8.h", "common.h", "api.hip", "conv8_inst_f32.hip", "conv_inst_bf16_k35.hip")   # what the dominant kernels are built from
 
 
 def kernel_source_digest() -> str:
@@ -178,7 +190,8 @@ def hbm_traffic(tag, avg_launch_us):
             rec = json.load(f)
     except (OSError, ValueError):
         return None, None
-    if rec.get("kernel") != tag:
+    rec = rec.get(tag) if "kernel" not in rec else (rec if rec.get("kernel") == tag else None)     # r03: one record per kernel tag
+    if not rec:
         return None, None
     rel = os.path.relpath(TRAFFIC_PROFILE, ROOT)
     try:
@@ -194,8 +207,49 @@ def hbm_traffic(tag, avg_launch_us):
 
 def executed_share(rows: int) -> float:
     """Share of the nominal 3x5 MFMAs that are issued: the (kernel row, output row) pairs that only see the zero row
-    above / below the image are left out at compile time -- 2 of 3*H pairs."""
+    above / below the image are left out at compile time -- 2 of 3*H pairs (conv_igemm.h, conv_igemm8.h, conv_wgrad.h)."""
     return 1.0 - 2.0 / (3.0 * rows)
+
+
+def executed_flop(tag: str, nominal: float, rows: int) -> float:
+    """FLOP of the MFMAs a launch issues, from its PyTorch-convention count: only the 3x5 implicit-GEMM kernels skip."""
+    return nominal * executed_share(rows) if "3x5" in tag else nominal
+
+
+def fwd_flop(rows: int, executed: bool) -> float:
+    """Forward FLOP per profile: nominal or as issued (3x5 layers past the first x executed_share)."""
+    skip = (CONV35_FLOP_H5 - FIRST_FLOP_H5) * (1.0 - executed_share(rows)) if executed else 0.0
+    return (FWD_FLOP_H5 - skip) * rows / 5
+
+
+def train_flop(rows: int, executed: bool) -> float:
+    """fwd + dgrad + wgrad FLOP per profile; forward, data gradient and weight gradient all skip the same pairs."""
+    skip = 3 * (CONV35_FLOP_H5 - FIRST_FLOP_H5) * (1.0 - executed_share(rows)) if executed else 0.0
+    return (TRAIN_FLOP_H5 - skip) * rows / 5
+
+
+def roofline_of(prof, dtype, rows, elapsed, pick=None):
+    """Roofline record of the kernel with the largest total time (or the tag containing ``pick``) from per-launch
+    (tag, nominal FLOP, start event, end event) records; returns (record, {tag: [nominal, executed, seconds, launches]})."""
+    by_tag = {}
+    for tag, flops, e0, e1 in prof:
+        d = by_tag.setdefault(tag, [0.0, 0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += executed_flop(tag, flops, rows)
+        d[2] += e0.elapsed_time(e1) * 1e-3
+        d[3] += 1
+    if not by_tag:
+        return None, by_tag
+    cands = {k: v for k, v in by_tag.items() if pick in k} if pick else by_tag
+    tag, (nominal, executed, sec, cnt) = max((cands or by_tag).items(), key=lambda kv: kv[1][2])
+    peak = peak_of(dtype)
+    rec = {"bound": "mfma", "kernel": tag, "achieved": round(executed / sec / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+           "frac": round(executed / sec / 1e12 / peak, 4), "frac_nominal": round(nominal / sec / 1e12 / peak, 4),
+           "achieved_nominal": round(nominal / sec / 1e12, 1),
+           "flop_basis": "MFMAs issued (3x5 kernels skip the all-zero halo-row pairs: 2 of 3*H); *_nominal = PyTorch-convention FLOP",
+           "traffic": None, "traffic_source": None, "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
+           "share_of_step_time": round(sec / elapsed, 3) if elapsed else None}
+    return rec, by_tag
 
 
 def make_eval_model(dtype, dev):
@@ -229,30 +283,32 @@ def infer_leg(dtype, rows, batch, steps, warmup, dev, rank, world, barrier, redu
     elapsed = reduce_max(time.perf_counter() - t0)
     prof, model.profile = model.profile or [], None
     value = batch * world * steps / elapsed
-    flop_per_profile = FWD_FLOP_H5 * rows / 5
-    by_tag = {}
-    for tag, flops, e0, e1 in prof:
-        d = by_tag.setdefault(tag, [0.0, 0.0, 0])
-        d[0] += flops
-        d[1] += e0.elapsed_time(e1) * 1e-3
-        d[2] += 1
-    roofline = None
-    if by_tag:
-        tag, (fl, sec, cnt) = max(by_tag.items(), key=lambda kv: kv[1][1])
+    roofline, by_tag = roofline_of(prof, dtype, rows, elapsed)
+    if roofline:
         peak = peak_of(dtype)
-        achieved = fl / sec / 1e12
-        traffic, source = hbm_traffic(tag, sec / cnt * 1e6) if (dtype, rows, batch) == ("bf16", 6, 256) else (None, None)
-        conv_fl = sum(v[0] for v in by_tag.values())
-        conv_sec = sum(v[1] for v in by_tag.values())
-        roofline = {"bound": "mfma", "kernel": tag, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "frac_executed_mfma": round(achieved / peak * executed_share(rows), 4),
-                    "traffic": traffic, "traffic_source": source, "launches": cnt,
-                    "avg_launch_us": round(sec / cnt * 1e6, 2), "share_of_step_time": round(sec / elapsed, 3),
-                    "all_conv_layers_frac": round(conv_fl / conv_sec / 1e12 / peak, 4),
-                    "whole_net_frac": round(value / world * flop_per_profile / 1e12 / peak, 4)}
+        if rows == 6 and batch == 256 and dtype in ("fp32", "bf16"):
+            roofline["traffic"], roofline["traffic_source"] = hbm_traffic(roofline["kernel"], roofline["avg_launch_us"])
+        conv_sec = sum(v[2] for v in by_tag.values())
+        roofline.update({
+            "all_conv_layers_frac": round(sum(v[1] for v in by_tag.values()) / conv_sec / 1e12 / peak, 4),
+            "all_conv_layers_frac_nominal": round(sum(v[0] for v in by_tag.values()) / conv_sec / 1e12 / peak, 4),
+            "whole_net_frac": round(value / world * fwd_flop(rows, True) / 1e12 / peak, 4),
+            "whole_net_frac_nominal": round(value / world * fwd_flop(rows, False) / 1e12 / peak, 4)})
+    stats = model.arena_stats()
     del model, x
     torch.cuda.empty_cache()
+    if roofline:
+        roofline["arena"] = stats
     return value, elapsed / steps * 1e3, roofline
+
+
+ALLOC_KEYS = {"hipMalloc_calls": "num_device_alloc", "hipFree_calls": "num_device_free", "alloc_retries": "num_alloc_retries",
+              "allocator_requests": "allocation.all.allocated"}
+
+
+def alloc_snapshot(dev):
+    st = torch.cuda.memory_stats(dev)
+    return {k: int(st.get(v, 0)) for k, v in ALLOC_KEYS.items()}
 
 
 def train_leg(dtype, rows, batch, steps, dev, rank, world, distributed, barrier, reduce_max, label=""):
@@ -283,12 +339,46 @@ def train_leg(dtype, rows, batch, steps, dev, rank, world, distributed, barrier,
     for _ in range(2):
         sums = step()
     barrier()
+    torch.cuda.reset_peak_memory_stats(dev)
+    before = alloc_snapshot(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(steps):
         sums = step()
+    ev1.record()
     loss = float(sums[4])              # the per-step host sync of the reference loop (trainable_unet.py:347), once here
     barrier()
     elapsed = reduce_max(time.perf_counter() - t0)
+    event_ms = ev0.elapsed_time(ev1)
+    after = alloc_snapshot(dev)
+    allocator = {k: after[k] - before[k] for k in after}
+    allocator["reserved_peak_GiB"] = round(torch.cuda.memory_stats(dev).get("reserved_bytes.all.peak", 0) / 2**30, 2)
+    allocator["arena"] = model.arena_stats()
+    # roofline of the step's dominant kernel: two more steps with per-launch HIP events (profiling keeps the weight
+    # gradients on the main stream, so durations are not stretched by overlap); outside the timed region
+    roofline = None
+    if not distributed:
+        model.profile = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof, model.profile = model.profile, None
+        roofline, by_tag = roofline_of(prof, dtype, rows, None, pick="conv_wgrad")
+        if roofline:
+            if rows == 6 and batch == 256:
+                roofline["traffic"], roofline["traffic_source"] = hbm_traffic(roofline["kernel"], roofline["avg_launch_us"])
+            roofline["share_of_step_time"] = round(by_tag[roofline["kernel"]][2] / 2 / (elapsed / steps), 3)
+            roofline["note"] = ("event pairs bracket dn_conv2d_wgrad = the split-K GEMM + its fixed-order slab reduction; "
+                                "share_of_step_time is single-stream kernel time over the two-stream step time")
+            peak = peak_of(dtype)
+            groups = {}
+            for tag, v in by_tag.items():
+                g = "weight_gradient" if "wgrad" in tag else "data_gradient" if tag.endswith(":dgrad") else "forward_with_statistics"
+                a = groups.setdefault(g, [0.0, 0.0, 0.0])
+                a[0] += v[1]; a[1] += v[0]; a[2] += v[2]
+            roofline["groups"] = {g: {"ms_per_step": round(a[2] / 2 * 1e3, 3), "frac": round(a[0] / a[2] / 1e12 / peak, 4),
+                                      "frac_nominal": round(a[1] / a[2] / 1e12 / peak, 4)} for g, a in groups.items()}
     if distributed:
         buckets = trainer.reducer.last_buckets
         comm = {"backend": dist.get_backend(), "world_size_seen_by_rank0": dist.get_world_size(),
@@ -300,10 +390,59 @@ def train_leg(dtype, rows, batch, steps, dev, rank, world, distributed, barrier,
            "rows": rows, "loss": round(loss, 5),
            "parallelism": f"dp{world}" + (f" ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} sum-all-reduce of Dice sums "
                                           "+ bucketed gradient arena)" if distributed else ""),
-           "whole_step_mfma_frac": round(pps / world * TRAIN_FLOP_H5 * rows / 5 / 1e12 / peak_of(dtype), 4)}
+           "event_ms_per_step": round(event_ms / steps, 3),
+           "event_vs_wall": round(event_ms / steps / (elapsed / steps * 1e3), 4),
+           "allocator_in_timed_region": allocator,
+           "whole_step_mfma_frac": round(pps / world * train_flop(rows, True) / 1e12 / peak_of(dtype), 4),
+           "whole_step_mfma_frac_nominal": round(pps / world * train_flop(rows, False) / 1e12 / peak_of(dtype), 4),
+           "roofline": roofline}
     if comm:
         out["comm"] = comm
     del model, opt, x, t
+    torch.cuda.empty_cache()
+    return out
+
+
+def fit_leg(dtype, dev, epochs=4, profiles=348, batch=16, rows=5):
+    """BASELINE.json configs[2] on ``fit()``'s own path (reference: train.py -> trainable_unet.py:183-203,339-347 with
+    config/training/segmentation.yaml: batch 16, lr 1e-4, scheduler on): 348 synthetic profiles tensorised once and kept in
+    HBM, 348 // 16 = 21 steps per epoch (the 12-profile tail is never trained on), the step replayed from a HIP graph.
+    Epoch 1 carries the eager warm-up step and the capture; the figure is the median of the later epochs, timed around
+    ``DNANet_UNet.epoch`` (per-step loss read-back and accuracy bookkeeping included)."""
+    from dnanet_amd.data import SyntheticDataset
+    from dnanet_amd.model import DNANet_UNet
+    ds = SyntheticDataset(profiles, rows, 4096, seed=3)
+    torch.manual_seed(0)
+    m = DNANet_UNet(4, (3, 5), 32, device=str(dev), apply_allele_caller=False, dtype=dtype)
+    times, losses = [], []
+    inner = m.epoch
+
+    def timed_epoch(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = inner(*a, **k)
+        torch.cuda.synchronize()
+        if k.get("train", True):
+            times.append(time.perf_counter() - t0)
+            losses.append(loss)
+        return loss
+
+    m.epoch = timed_epoch
+    before = alloc_snapshot(dev)
+    m.fit(ds, batch_size=batch, num_epochs=epochs, learning_rate=1e-4, use_scheduler=True, use_evaluation_metric=True)
+    after = alloc_snapshot(dev)
+    steps = profiles // batch
+    steady = sorted(times[1:])
+    t = steady[len(steady) // 2]
+    out = {"value": round(steps * batch / t, 1), "unit": "profiles/s", "dtype": "bf16" if dtype == "bf16" else "f32",
+           "ms_per_step": round(t / steps * 1e3, 3), "ms_per_epoch": round(t * 1e3, 2), "first_epoch_ms": round(times[0] * 1e3, 1),
+           "epochs_timed": len(steady), "steps_per_epoch": steps, "batch": batch, "profiles": profiles,
+           "profiles_never_trained_on": profiles - steps * batch, "rows": rows,
+           "path": "DNANet_UNet.fit(): resident set + HIP-graph replay of the whole step (trainable_unet.py:183-203,339-347)",
+           "epoch_losses": [round(float(l), 5) for l in losses],
+           "whole_step_mfma_frac": round(steps * batch / t * train_flop(rows, True) / 1e12 / peak_of(dtype), 4),
+           "allocator_whole_fit": {k: after[k] - before[k] for k in after}}
+    del m, ds
     torch.cuda.empty_cache()
     return out
 
@@ -423,7 +562,10 @@ def main():
         "config": {"workload": f"U-Net depth4 k(3,5) f32 eval forward, batch {args.batch}/GPU, {args.rows} dyes x 4096 scans "
                                f"(BASELINE.json configs[1], {args.dtype} half)", "global_batch": args.batch * world,
                    "parallelism": f"replicas x{world} (inference shards by profile, no collective)",
-                   "world_size_seen_by_rank0": world, **({"backend": args.backend, "devices": ndev} if distributed else {})},
+                   "world_size_seen_by_rank0": world, **({"backend": args.backend, "devices": ndev} if distributed else {}),
+                   "precision": "fp32 = the reference's arithmetic; masks and called alleles identical to the reference "
+                                "(tests/test_parity_bf16_gpu.py, tests/test_shipped_golden_gpu.py); bf16 / bf16x3 are under legs"
+                                if args.dtype == "fp32" else f"{args.dtype} (not the parity mode: see parity)"},
         "roofline": roofline,
     }
     if not args.no_legs and not distributed:
@@ -434,7 +576,7 @@ def main():
         todo = {f"infer_{dt(d)}_h{args.rows}": (d, args.rows) for d in ("fp32", "bf16", "bf16x3", "bf16x3@2") if d != args.dtype}
         todo.update({f"infer_{dt(d)}_h5": (d, 5) for d in ("bf16", "fp32", "bf16x3") if (d, 5) != (args.dtype, args.rows)})
         for name, (d, rows) in todo.items():
-            steps = max(3, args.steps // 4) if d == "fp32" else max(5, args.steps // 2)
+            steps = max(3, args.steps // 2) if d == "fp32" else max(5, args.steps)
             v, m, r = infer_leg(d, rows, args.batch, steps, min(2, args.warmup), *common)
             legs[name] = {"value": round(v, 1), "unit": "profiles/s", "dtype": dt(d), "rows": rows, "batch": args.batch,
                           "steps": steps, "ms_per_step": round(m, 3), "roofline": r}
@@ -455,8 +597,13 @@ def main():
                 out["train_step_global"] = {"error": f"{type(exc).__name__}: {exc}"[:300], "per_gpu_batch": per}
         if not distributed and not args.no_legs:
             other = "fp32" if args.dtype == "bf16" else "bf16"
-            out[f"train_step_{dt(other)}"] = train_leg(other, args.rows, args.batch, 3, dev, rank, world, False, barrier, reduce_max)
-            out["train_step_bf16_h5"] = train_leg("bf16", 5, args.batch, tsteps, dev, rank, world, False, barrier, reduce_max)
+            osteps = tsteps if other == "fp32" else max(5, args.steps // 2)
+            out[f"train_step_{dt(other)}"] = train_leg(other, args.rows, args.batch, osteps, dev, rank, world, False, barrier, reduce_max)
+            out["train_step_bf16_h5"] = train_leg("bf16", 5, args.batch, max(5, args.steps // 2), dev, rank, world, False, barrier, reduce_max)
+            out["train_step_f32_h5"] = train_leg("fp32", 5, args.batch, tsteps, dev, rank, world, False, barrier, reduce_max)
+            # configs[2]: fit() at train.py's batch of 16 over 348 profiles
+            out["train_step_n16_h5"] = fit_leg("fp32", dev)
+            out["train_step_n16_h5_bf16"] = fit_leg("bf16", dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.rows)
     if rank == 0:

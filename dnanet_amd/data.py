@@ -142,6 +142,12 @@ class ArrayDataset(Sequence):
     def __init__(self, data: Sequence = (), shuffle: bool = False, group_replicas_in_split: bool = False):
         self._data = list(data)
         self.shuffle = shuffle
+        # Shuffled iteration inside a multi-rank job: every rank must walk the epochs in the same order (fit() slices each
+        # batch by rank).  The agreement is ONE collective, here at construction (every rank builds the same datasets in
+        # the same order); __iter__ itself never communicates, so a rank may iterate on its own (rank 0 scoring in
+        # evaluate.py) without anybody joining.  Outside a group: a fresh generator per iteration, as the reference.
+        seed = shared_seed(None) if shuffle else None
+        self._rng = random.Random(seed) if seed is not None else None
         # the `group_replicas_in_split` key of the reference's data configs (``config/data/dnanet_rd.yaml``,
         # ``hid_dataset.py:344-412``): replicas of one mixture (file names sharing the prefix "1A2") stay on one side of a
         # split and every number of contributors (the prefix's last digit) is divided in the same proportion
@@ -155,8 +161,7 @@ class ArrayDataset(Sequence):
 
     def __iter__(self):
         if self.shuffle:
-            seed = shared_seed(None)
-            rng = random.Random(seed) if seed is not None else random
+            rng = self._rng or random.Random()              # base.py:62 of the reference: random.Random().sample(...)
             return iter(rng.sample(self._data, len(self._data)))
         return iter(self._data)
 

@@ -174,13 +174,75 @@ def planes(c: int, dtype: int) -> int:
     return (c + e - 1) // e
 
 
-class PlaneBuffer:
-    """A plane-record activation buffer [N][planes][H][W][epr] owned by torch's allocator."""
+class StepArena:
+    """The device memory of one pass (a training step: forward + backward; or an eval forward) at one batch shape.
 
-    def __init__(self, n: int, planes_total: int, h: int, w: int, dtype: int, device, zero: bool = False):
+    A pass asks for its buffers in the same order every time, so slot i of the arena IS the i-th buffer of the pass:
+    the first pass at a shape allocates, every later one gets the same tensors back -- no allocator call, no
+    ``hipMalloc``, no ``record_stream`` bookkeeping in steady state, and fixed addresses for HIP-graph replay.  By default
+    nothing is shared between slots inside a pass; the price is that a pass holds the sum of its buffers (~130 MB per
+    bf16 6-dye profile for a training step), which is what 288 GB of HBM is for.  A caller whose pass runs on ONE stream
+    may ``release`` a buffer it is done with: a later ``take`` of the same shape inside the pass gets it back (stream
+    order makes that safe; with the weight gradients on a second stream nothing is released).  Releases happen at the
+    same points of every pass, so the slot sequence stays the same.  Contents do not survive ``begin()``."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.slots = []
+        self.cursor = 0
+        self.allocations = 0        # slots ever created (steady state: constant)
+        self.passes = 0
+        self._free = {}
+
+    def begin(self) -> "StepArena":
+        self.cursor = 0
+        self.passes += 1
+        self._free = {}
+        return self
+
+    def release(self, t: torch.Tensor):
+        """``t`` (handed out by ``take`` in this pass) may be handed out again; only for single-stream passes."""
+        self._free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+    def take(self, shape, dtype, zero: bool = False) -> torch.Tensor:
+        shape = tuple(int(v) for v in shape)
+        free = self._free.get((shape, dtype))
+        if free:
+            t = free.pop()
+            if zero:
+                t.zero_()
+            return t
+        i = self.cursor
+        self.cursor += 1
+        if i < len(self.slots):
+            t = self.slots[i]
+            if tuple(t.shape) == shape and t.dtype == dtype:
+                if zero:
+                    t.zero_()
+                return t
+            del self.slots[i:]       # the pass took another route than last time (a key the owner did not foresee)
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        self.slots.append(t)
+        self.allocations += 1
+        return t
+
+    @property
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.slots)
+
+
+class PlaneBuffer:
+    """A plane-record activation buffer [N][planes][H][W][epr]: slot of a ``StepArena`` (the passes of ``HipUNet``) or a
+    tensor of torch's allocator (tests, one-off callers)."""
+
+    def __init__(self, n: int, planes_total: int, h: int, w: int, dtype: int, device, zero: bool = False,
+                 arena: "StepArena | None" = None):
         self.n, self.planes_total, self.h, self.w, self.dtype = n, planes_total, h, w, dtype
-        alloc = torch.zeros if zero else torch.empty
-        self.data = alloc((n, planes_total, h, w, epr(dtype)), dtype=torch_dtype(dtype), device=device)
+        shape = (n, planes_total, h, w, epr(dtype))
+        if arena is not None:
+            self.data = arena.take(shape, torch_dtype(dtype), zero)
+        else:
+            self.data = (torch.zeros if zero else torch.empty)(shape, dtype=torch_dtype(dtype), device=device)
 
     def ref(self, channels: int, plane0: int = 0) -> DnTensor:
         assert plane0 + planes(channels, self.dtype) <= self.planes_total

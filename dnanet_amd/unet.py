@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import hip
-from .hip import BF16, F32, PlaneBuffer
+from .hip import BF16, F32, PlaneBuffer, StepArena
 from .params import ConvUnit, ParameterTree
 
 BN_EPS = 1e-5       # nn.BatchNorm2d default used by the reference (unet_architecture.py:17,21)
@@ -81,6 +81,12 @@ class HipUNet(ParameterTree):
         # units on the main stream.  DN_TUNE_NO_WGRAD_STREAM=1 keeps everything on one stream (A/B switch).
         self.overlap_wgrad = self.flat_params.is_cuda and not os.environ.get("DN_TUNE_NO_WGRAD_STREAM")
         self._wgrad_stream = None
+        # Device memory of the passes: one StepArena per (kind of pass, batch shape), allocated by the first pass at that
+        # shape and reused by every later one (no allocator calls in steady state).  Least recently used arenas are
+        # dropped when the total passes ``arena_budget_bytes``.
+        self._arenas: Dict[tuple, StepArena] = {}
+        self._arena_override: Optional[StepArena] = None     # GraphedTrainStep: the captured step's own arena
+        self.arena_budget_bytes = int(os.environ.get("DN_ARENA_BUDGET_GIB", "160")) << 30
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -92,6 +98,28 @@ class HipUNet(ParameterTree):
     def _require_gpu(self, x: torch.Tensor):
         if not (self.device.type == "cuda" and x.is_cuda):
             raise RuntimeError("dnanet_amd runs on an MI355X only (no CPU fallback): model and input must be on 'cuda'")
+
+    def _arena(self, kind: str, n: int, h: int, w: int) -> StepArena:
+        """The arena of a ``kind`` pass at this batch shape, rewound to its first slot."""
+        if self._arena_override is not None:
+            return self._arena_override.begin()
+        key = (kind, n, h, w, self.dtype, self.split_levels, self.profile is not None, self.sync_bn is not None)
+        arena = self._arenas.pop(key, None)
+        if arena is None:
+            arena = StepArena(self.device)
+            total = sum(a.nbytes for a in self._arenas.values())
+            while self._arenas and total > self.arena_budget_bytes:
+                total -= self._arenas.pop(next(iter(self._arenas))).nbytes       # least recently used first
+        self._arenas[key] = arena          # most recently used last
+        return arena.begin()
+
+    def arena_stats(self) -> dict:
+        """{'arenas', 'bytes', 'allocations'}: ``allocations`` stops growing once every batch shape has been seen."""
+        arenas = list(self._arenas.values())
+        return {"arenas": len(arenas), "bytes": sum(a.nbytes for a in arenas), "allocations": sum(a.allocations for a in arenas)}
+
+    def release_arenas(self):
+        self._arenas.clear()
 
     def _pp(self, c: int) -> int:
         return hip.planes(c, self.dtype)
@@ -198,6 +226,19 @@ class HipUNet(ParameterTree):
         hip.check(hip.lib.dn_conv2d_variant(cin, cout, n, h, w, kh, kw, self.dtype, buf, len(buf)))
         return buf.value.decode()
 
+    def _timed(self, tag, flops: float, launch):
+        """``launch()``; with ``self.profile`` a list, bracketed by HIP events on the launch stream and recorded as
+        (kernel tag, nominal FLOP, start, end) -- what bench.py's roofline figures are computed from.  ``tag`` may be a
+        callable (only evaluated when profiling)."""
+        if self.profile is None:
+            launch()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self.profile.append((tag() if callable(tag) else tag, flops, e0, e1))
+
     def _conv(self, u: ConvUnit, entry, src, dst, n, h, w, relu=1, pooled=None):
         """``pooled``: also write MaxPool2d((1,2)) of the output there (fused epilogue, ``dn_conv2d_pool``)."""
         if self.profile is not None and u.cin != 1:
@@ -234,31 +275,40 @@ class HipUNet(ParameterTree):
         ws = [w >> l for l in range(depth + 1)]
         cache = self._eval_cache
         units = {u.conv: u for u in self.conv_units}
-        cat = [PlaneBuffer(n, 2 * self._pp(c[l]), h, ws[l], dt, dev) for l in range(depth)]
+        A = self._arena("eval", n, h, w)
+        cat = [PlaneBuffer(n, 2 * self._pp(c[l]), h, ws[l], dt, dev, arena=A) for l in range(depth)]
         cur = x
         for l in range(depth):
             pre = f"encoders.{l}.conv.double_conv"
-            tmp = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            tmp = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev, arena=A)
             self._conv(units[pre + ".0"], cache[pre + ".0"], cur if l == 0 else cur.ref(c[l - 1]), tmp.ref(c[l]), n, h, ws[l])
             skip = cat[l].ref(c[l], self._pp(c[l]))
-            pooled = PlaneBuffer(n, self._pp(c[l]), h, ws[l + 1], dt, dev)
+            pooled = PlaneBuffer(n, self._pp(c[l]), h, ws[l + 1], dt, dev, arena=A)
             self._conv(units[pre + ".3"], cache[pre + ".3"], tmp.ref(c[l]), skip, n, h, ws[l], pooled=pooled.ref(c[l]))
+            # an eval pass runs on one stream: a buffer whose reader has been queued can serve a later layer of the pass
+            A.release(tmp.data)
+            if l > 0:
+                A.release(cur.data)
             cur = pooled
         pre = "bottleneck.double_conv"
-        tmp = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev)
+        tmp = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev, arena=A)
         self._conv(units[pre + ".0"], cache[pre + ".0"], cur.ref(c[depth - 1]), tmp.ref(c[depth]), n, h, ws[depth])
-        out = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev)
+        A.release(cur.data)
+        out = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev, arena=A)
         self._conv(units[pre + ".3"], cache[pre + ".3"], tmp.ref(c[depth]), out.ref(c[depth]), n, h, ws[depth])
+        A.release(tmp.data)
         cur = out
         for i in range(depth):
             l = depth - 1 - i
             up = cache[f"decoders.{i}.up"]
             hip.check(hip.lib.dn_conv_transpose_1x2(cur.ref(c[l + 1]), hip.ptr(up["w"]), hip.ptr(up["bias"]),
                                                     cat[l].ref(c[l], 0), n, h, ws[l + 1], dt, hip.stream_ptr()))
+            A.release(cur.data)
             pre = f"decoders.{i}.conv.double_conv"
-            tmp = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            tmp = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev, arena=A)
             both = cat[l].ref(2 * self._cpad_planes(c[l]), 0)
             self._conv(units[pre + ".0"], cache[pre + ".0"], both, tmp.ref(c[l]), n, h, ws[l])
+            A.release(cat[l].data)
             last = units[pre + ".3"]
             kh, kw = self.kernel_size
             if l == 0 and hip.lib.dn_conv2d_head_supported(last.cin, last.cout, n, h, w, kh, kw, dt):
@@ -275,8 +325,9 @@ class HipUNet(ParameterTree):
                     self.profile.append((self.conv_kernel_tag(last.cin, last.cout, n, h, w) + "+head",
                                          2.0 * n * h * w * last.cout * (last.cin * kh * kw + 1), e0, e1))
                 return
-            out = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            out = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev, arena=A)
             self._conv(last, cache[pre + ".3"], tmp.ref(c[l]), out.ref(c[l]), n, h, ws[l])
+            A.release(tmp.data)
             cur = out
         hip.check(hip.lib.dn_head_1x1(cur.ref(c[0]), hip.ptr(cache["head_w"]), hip.ptr(cache["head_b"]),
                                       hip.ptr(logits), hip.ptr(probs), n, h, w, dt, hip.stream_ptr()))
@@ -296,10 +347,11 @@ class HipUNet(ParameterTree):
         cache = self._eval_cache
         units = {u.conv: u for u in self.conv_units}
         stream = hip.stream_ptr()
+        A = self._arena("eval", n, h, w)
 
         def act(l, chan_level, units_wide=1):
             """buffer for `units_wide` tensors of c[chan_level] channels at level l's width and precision"""
-            return PlaneBuffer(n, units_wide * P[chan_level] * (2 if S(l) else 1), h, ws[l], dt, dev)
+            return PlaneBuffer(n, units_wide * P[chan_level] * (2 if S(l) else 1), h, ws[l], dt, dev, arena=A)
 
         def r3(buf, l, channels, plane0, hi_planes):
             return buf.ref3(channels, plane0, hi_planes if S(l) else 0)
@@ -482,16 +534,16 @@ class HipUNet(ParameterTree):
     def _unit_forward(self, u: ConvUnit, src, dst, n, h, w, raw_x=None, pooled=None):
         """conv + bias -> y ; batch-stat BatchNorm + ReLU -> dst (and MaxPool2d((1,2)) of it -> pooled).  Saves what
         backward needs."""
-        ws, cache = self._workspace(), self._train_cache
-        y = PlaneBuffer(n, self._pp(u.cout), h, w, self.dtype, self.device)
+        ws, cache, A = self._workspace(), self._train_cache, self._saved["arena"]
+        y = PlaneBuffer(n, self._pp(u.cout), h, w, self.dtype, self.device, arena=A)
         cp = hip.channel_pad(u.cout)
-        vec = torch.empty(4 * cp, dtype=torch.float32, device=self.device)
+        vec = A.take((4 * cp,), torch.float32)
         mean, invstd, scale, shift = (vec[i * cp:(i + 1) * cp] for i in range(4))
         bn_args = (hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(self.tensor(u.bn + ".bias")),
                    hip.ptr(self.tensor(u.bn + ".running_mean")), hip.ptr(self.tensor(u.bn + ".running_var")), BN_MOMENTUM, BN_EPS,
                    hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift))
         kh, kw = self.kernel_size
-        if (kh, kw) in ((3, 5), (1, 3)) and self.profile is None:
+        if (kh, kw) in ((3, 5), (1, 3)):
             # the batch statistics come out of the convolution's epilogue: one pass over y saved
             # tiles are at least 3 rows x 128 columns (the first convolution may tile row by row)
             need = n * (h if u.cin == 1 else (h + 2) // 3) * ((w + 127) // 128) * cp * 2
@@ -499,18 +551,20 @@ class HipUNet(ParameterTree):
                 ws["bnstat"] = torch.empty(need, dtype=torch.float32, device=self.device)
             ntiles = ctypes.c_int(0)
             entry = cache[u.conv]
+            flops = 2.0 * n * h * w * u.cout * u.cin * kh * kw
             if u.cin == 1:
-                hip.check(hip.lib.dn_conv_first_stats(hip.ptr(raw_x), hip.ptr(entry["wf"]), hip.ptr(entry["bias"]), y.ref(u.cout),
-                                                      n, h, w, u.cout, kh, kw, self.dtype, hip.ptr(ws["bnstat"]),
-                                                      ws["bnstat"].numel(), ctypes.byref(ntiles), hip.stream_ptr()))
+                self._timed("conv_first+stats", flops, lambda: hip.check(hip.lib.dn_conv_first_stats(
+                    hip.ptr(raw_x), hip.ptr(entry["wf"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, u.cout, kh, kw, self.dtype,
+                    hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles), hip.stream_ptr())))
             else:
-                hip.check(hip.lib.dn_conv2d_stats(src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, kh, kw,
-                                                  self.dtype, hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles),
-                                                  hip.stream_ptr()))
+                self._timed(lambda: self.conv_kernel_tag(u.cin, u.cout, n, h, w) + "+stats", flops,
+                            lambda: hip.check(hip.lib.dn_conv2d_stats(
+                                src, hip.ptr(entry["w"]), hip.ptr(entry["bias"]), y.ref(u.cout), n, h, w, kh, kw, self.dtype,
+                                hip.ptr(ws["bnstat"]), ws["bnstat"].numel(), ctypes.byref(ntiles), hip.stream_ptr())))
             if self.sync_bn is not None:
                 # batch statistics of the GLOBAL batch: this rank's per-channel totals (fp64) are summed over the group
                 all_reduce, world = self.sync_bn
-                totals = torch.empty(2 * cp, dtype=torch.float64, device=self.device)
+                totals = A.take((2 * cp,), torch.float64)
                 hip.check(hip.lib.dn_bn_partial_totals(hip.ptr(ws["bnstat"]), ntiles.value, u.cout, hip.ptr(totals), hip.stream_ptr()))
                 all_reduce(totals)
                 hip.check(hip.lib.dn_bn_train_apply_totals(y.ref(u.cout), dst, pooled if pooled is not None else hip.DnTensor(None, 0, 0, 0),
@@ -524,8 +578,7 @@ class HipUNet(ParameterTree):
                                                     self.dtype, hip.stream_ptr()))
         else:
             if self.sync_bn is not None:
-                raise NotImplementedError("synchronised BatchNorm needs the fused-statistics convolutions: kernel sizes (3,5) / "
-                                          "(1,3), and no per-launch profiling")
+                raise NotImplementedError("synchronised BatchNorm needs the fused-statistics convolutions: kernel sizes (3,5) / (1,3)")
             self._conv(u, cache[u.conv], raw_x if u.cin == 1 else src, y.ref(u.cout), n, h, w, relu=0)
             hip.check(hip.lib.dn_bn_train_forward(y.ref(u.cout), dst, n, h, w, *bn_args, hip.ptr(ws["partial"]), self.dtype,
                                                   hip.stream_ptr()))
@@ -547,23 +600,24 @@ class HipUNet(ParameterTree):
         c = [f * 2 ** l for l in range(depth + 1)]
         ws = [w >> l for l in range(depth + 1)]
         units = {u.conv: u for u in self.conv_units}
-        S = self._saved = {"x": x, "n": n, "h": h, "w": w}
-        cat = [PlaneBuffer(n, 2 * self._pp(c[l]), h, ws[l], dt, dev) for l in range(depth)]
+        A = self._arena("train", n, h, w)
+        S = self._saved = {"x": x, "n": n, "h": h, "w": w, "arena": A}
+        cat = [PlaneBuffer(n, 2 * self._pp(c[l]), h, ws[l], dt, dev, arena=A) for l in range(depth)]
         S["cat"] = cat
         cur = None
         for l in range(depth):
             pre = f"encoders.{l}.conv.double_conv"
-            a1 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            a1 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev, arena=A)
             self._unit_forward(units[pre + ".0"], None if l == 0 else cur, a1.ref(c[l]), n, h, ws[l], raw_x=x)
             skip = cat[l].ref(c[l], self._pp(c[l]))
-            pooled = PlaneBuffer(n, self._pp(c[l]), h, ws[l + 1], dt, dev)
+            pooled = PlaneBuffer(n, self._pp(c[l]), h, ws[l + 1], dt, dev, arena=A)
             self._unit_forward(units[pre + ".3"], a1.ref(c[l]), skip, n, h, ws[l], pooled=pooled.ref(c[l]))
             S[f"pooled{l}"] = pooled
             cur = pooled.ref(c[l])
         pre = "bottleneck.double_conv"
-        a1 = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev)
+        a1 = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev, arena=A)
         self._unit_forward(units[pre + ".0"], cur, a1.ref(c[depth]), n, h, ws[depth])
-        a2 = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev)
+        a2 = PlaneBuffer(n, self._pp(c[depth]), h, ws[depth], dt, dev, arena=A)
         self._unit_forward(units[pre + ".3"], a1.ref(c[depth]), a2.ref(c[depth]), n, h, ws[depth])
         cur, cur_buf = a2.ref(c[depth]), a2
         for i in range(depth):
@@ -573,10 +627,10 @@ class HipUNet(ParameterTree):
             hip.check(hip.lib.dn_conv_transpose_1x2(cur, hip.ptr(up["w"]), hip.ptr(up["bias"]), cat[l].ref(c[l], 0), n, h,
                                                     ws[l + 1], dt, hip.stream_ptr()))
             pre = f"decoders.{i}.conv.double_conv"
-            a1 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            a1 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev, arena=A)
             both = cat[l].ref(2 * self._cpad_planes(c[l]), 0)
             self._unit_forward(units[pre + ".0"], both, a1.ref(c[l]), n, h, ws[l])
-            a2 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev)
+            a2 = PlaneBuffer(n, self._pp(c[l]), h, ws[l], dt, dev, arena=A)
             self._unit_forward(units[pre + ".3"], a1.ref(c[l]), a2.ref(c[l]), n, h, ws[l])
             cur, cur_buf = a2.ref(c[l]), a2
         S["head_in"], S["keep"] = cur, cur_buf
@@ -618,10 +672,10 @@ class HipUNet(ParameterTree):
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         return self._wgrad_stream
 
-    def _launch_wgrad(self, launch, *refs):
-        """``launch()`` on the weight-gradient stream, ordered after everything queued on the current stream so far.
-        ``refs``: the plane-record tensors it reads -- the allocator must not hand their memory to a later main-stream
-        allocation while the side stream still reads them."""
+    def _launch_wgrad(self, launch):
+        """``launch()`` on the weight-gradient stream, ordered after everything queued on the current stream so far.  What
+        it reads are slots of the step's arena: nothing else is handed that memory before the pass ends, and backward()
+        joins the side stream before it returns (so the next pass, which reuses the slots, is ordered after it)."""
         side = self._side()
         if side is None:
             launch()
@@ -629,8 +683,6 @@ class HipUNet(ParameterTree):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             launch()
-        for r in refs:
-            r._owner.data.record_stream(side)
 
     def _segment_done(self, segment_hook, name):
         """Tell a data-parallel reducer that the gradients of ``name`` are final: on a stream that is ordered after both the
@@ -645,16 +697,17 @@ class HipUNet(ParameterTree):
 
     def _unit_backward(self, u: ConvUnit, g, want_dgrad: bool):
         """g: dL/d(output activation) in a buffer (overwritten with dL/dy). Returns dL/d(input) ref."""
-        ws, cache, sv = self._workspace(), self._train_cache, self._saved[u.conv]
+        ws, cache, sv, A = self._workspace(), self._train_cache, self._saved[u.conv], self._saved["arena"]
         n, h, w = sv["n"], sv["h"], sv["w"]
         kh, kw = self.kernel_size
         if self.sync_bn is not None:
             all_reduce, world = self.sync_bn
-            local = torch.empty(2 * hip.channel_pad(u.cout), dtype=torch.float64, device=self.device)
+            local = A.take((2 * hip.channel_pad(u.cout),), torch.float64)
             hip.check(hip.lib.dn_bn_train_backward_totals(g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
                                                           hip.ptr(sv["mean"]), hip.ptr(sv["invstd"]), hip.ptr(ws["partial"]),
                                                           hip.ptr(local), self.dtype, hip.stream_ptr()))
-            total = local.clone()
+            total = A.take(tuple(local.shape), torch.float64)
+            total.copy_(local)
             all_reduce(total)
             hip.check(hip.lib.dn_bn_train_backward_apply_totals(
                 g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w, hip.ptr(self.tensor(u.bn + ".weight")),
@@ -673,15 +726,18 @@ class HipUNet(ParameterTree):
                                                   hip.ptr(ws["partial"]), ws["partial"].numel(), n, h, w, kh, kw, self.dtype,
                                                   hip.stream_ptr()))
             return None
-        self._launch_wgrad(lambda: hip.check(hip.lib.dn_conv2d_wgrad(
+        flops = 2.0 * n * h * w * u.cout * u.cin * kh * kw
+        dt_name = "bf16" if self.dtype == BF16 else "f32"
+        # (the event pair of a profiled run brackets the split-K GEMM and its fixed-order reduction: one C entry point)
+        self._launch_wgrad(lambda: self._timed(f"conv_wgrad<{dt_name},{kh}x{kw}>", flops, lambda: hip.check(hip.lib.dn_conv2d_wgrad(
             g, sv["src"], hip.ptr(self.grad(u.conv + ".weight")), hip.ptr(ws["wgrad"]), ws["wgrad"].numel(), n, h, w, kh, kw,
-            u.cin, u.split, self.dtype, hip.stream_ptr())), g, sv["src"])
+            u.cin, u.split, self.dtype, hip.stream_ptr()))))
         if not want_dgrad:
             return None
         cin_stored = sv["src"].channels
-        gin = PlaneBuffer(n, self._pp(cin_stored), h, w, self.dtype, self.device)
-        hip.check(hip.lib.dn_conv2d(g, hip.ptr(cache[u.conv]["wd"]), None, gin.ref(cin_stored), n, h, w, kh, kw, 0, self.dtype,
-                                    hip.stream_ptr()))
+        gin = PlaneBuffer(n, self._pp(cin_stored), h, w, self.dtype, self.device, arena=A)
+        self._timed(lambda: self.conv_kernel_tag(u.cout, cin_stored, n, h, w) + ":dgrad", flops, lambda: hip.check(hip.lib.dn_conv2d(
+            g, hip.ptr(cache[u.conv]["wd"]), None, gin.ref(cin_stored), n, h, w, kh, kw, 0, self.dtype, hip.stream_ptr())))
         return gin
 
     def backward(self, dlogits: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None, segment_hook=None):
@@ -691,7 +747,7 @@ class HipUNet(ParameterTree):
         S = self._saved
         if S is None:
             raise RuntimeError("backward() needs a preceding train-mode forward")
-        ws = self._workspace()
+        ws, A = self._workspace(), S["arena"]
         n, h, w = S["n"], S["h"], S["w"]
         depth, f, dt, dev = self.depth, self.num_filters, self.dtype, self.device
         c = [f * 2 ** l for l in range(depth + 1)]
@@ -699,10 +755,10 @@ class HipUNet(ParameterTree):
         units = {u.conv: u for u in self.conv_units}
         if dlogits is None:
             sums = S["sums"] if sums is None else sums
-            dlogits = torch.empty_like(S["logits"])
+            dlogits = A.take(tuple(S["logits"].shape), S["logits"].dtype)
             hip.check(hip.lib.dn_dice_backward(hip.ptr(S["logits"]), hip.ptr(S["targets"]), dlogits.numel(), hip.ptr(sums),
                                                hip.ptr(dlogits), hip.stream_ptr()))
-        g = PlaneBuffer(n, self._pp(c[0]), h, w, dt, dev)
+        g = PlaneBuffer(n, self._pp(c[0]), h, w, dt, dev, arena=A)
         hip.check(hip.lib.dn_head_1x1_backward(hip.ptr(dlogits), S["head_in"], hip.ptr(self._train_cache["head_w"]), g.ref(c[0]),
                                                hip.ptr(self.grad("outputs.weight")), hip.ptr(self.grad("outputs.bias")),
                                                hip.ptr(ws["partial"]), n, h, w, dt, hip.stream_ptr()))
@@ -710,20 +766,25 @@ class HipUNet(ParameterTree):
             self._segment_done(segment_hook, "head")
         gcat = [None] * depth
         cur = g
+        # single-stream backward (profiling, big batches): a gradient buffer whose readers are all queued goes back to the
+        # arena for a later layer of this pass; with the weight gradients on a second stream nothing is shared
+        done = (lambda buf: A.release(buf.data)) if self._side() is None else (lambda buf: None)
         for i in reversed(range(depth)):
             l = depth - 1 - i
             pre = f"decoders.{i}.conv.double_conv"
             g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True)
+            done(cur)
             gcat[l] = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), True)
+            done(g1)
             d_up = gcat[l].ref(c[l], 0)
             upn = f"decoders.{i}.up"
             xin = S[f"up{i}_in"]
             self._launch_wgrad(lambda: hip.check(hip.lib.dn_conv_transpose_1x2_wgrad(
                 d_up, xin, hip.ptr(self.grad(upn + ".weight")), hip.ptr(ws["wgrad"]), ws["wgrad"].numel(), n, h, wl[l + 1], dt,
-                hip.stream_ptr())), d_up, xin)
+                hip.stream_ptr())))
             hip.check(hip.lib.dn_channel_sum(d_up, hip.ptr(self.grad(upn + ".bias")), hip.ptr(ws["partial"]), n, h, wl[l], dt,
                                              hip.stream_ptr()))
-            gx = PlaneBuffer(n, self._pp(c[l + 1]), h, wl[l + 1], dt, dev)
+            gx = PlaneBuffer(n, self._pp(c[l + 1]), h, wl[l + 1], dt, dev, arena=A)
             hip.check(hip.lib.dn_conv_transpose_1x2_dgrad(d_up, hip.ptr(self._train_cache[upn]["wd"]), gx.ref(c[l + 1]), n, h,
                                                           wl[l + 1], dt, hip.stream_ptr()))
             cur = gx
@@ -731,17 +792,23 @@ class HipUNet(ParameterTree):
                 self._segment_done(segment_hook, f"decoders.{i}")
         pre = "bottleneck.double_conv"
         g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[depth]), True)
+        done(cur)
         gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[depth]), True)
+        done(g1)
         if segment_hook:
             self._segment_done(segment_hook, "bottleneck")
         for l in reversed(range(depth)):
             pre = f"encoders.{l}.conv.double_conv"
             skip = S["cat"][l].ref(c[l], self._pp(c[l]))
-            g2 = PlaneBuffer(n, self._pp(c[l]), h, wl[l], dt, dev)
+            g2 = PlaneBuffer(n, self._pp(c[l]), h, wl[l], dt, dev, arena=A)
             hip.check(hip.lib.dn_maxpool_1x2_backward(skip, gpool.ref(c[l]), gcat[l].ref(c[l], self._pp(c[l])), g2.ref(c[l]), n, h,
                                                       wl[l + 1], dt, hip.stream_ptr()))
+            done(gpool)
+            done(gcat[l])
             g1 = self._unit_backward(units[pre + ".3"], g2.ref(c[l]), True)
+            done(g2)
             gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), l > 0)
+            done(g1)
             if segment_hook:
                 self._segment_done(segment_hook, f"encoders.{l}")
         if self._side() is not None:
@@ -793,8 +860,8 @@ class GraphedTrainStep:
     otherwise bound by the host issuing those launches (trainable_unet.py:339-347 is the loop being replaced).
 
     Batch shape, betas / eps / weight decay are frozen into the graph (``matches`` tells whether a batch fits); the
-    learning rate and the Adam step count live in device memory, so ExponentialLR keeps working.  The activations of
-    the step stay allocated in the graph's private pool (~70 MB per bf16 profile)."""
+    learning rate and the Adam step count live in device memory, so ExponentialLR keeps working.  The buffers of the
+    step (its own ``StepArena``) stay allocated in the graph's private pool (~110 MB per bf16 profile)."""
 
     def __init__(self, model: "HipUNet", optimizer: HipAdam, x: torch.Tensor, t: torch.Tensor):
         self.model, self.optimizer = model, optimizer
@@ -812,12 +879,19 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         saved_count, saved_epoch = optimizer.step_count, model._param_epoch
         torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph):
-            logits = model.forward_train(self.x)
-            self.sums = model.dice_forward(logits, self.t)
-            model.backward()
-            optimizer.step(device_state=(self.hyper, self.step_dev))
-            optimizer.zero_grad()
+        # the captured step owns its arena (allocated from the graph's private pool during the capture): the addresses
+        # the graph replays on stay valid whatever the model's own arenas do afterwards
+        self.arena = StepArena(model.device)
+        model._arena_override = self.arena
+        try:
+            with torch.cuda.graph(self.graph):
+                logits = model.forward_train(self.x)
+                self.sums = model.dice_forward(logits, self.t)
+                model.backward()
+                optimizer.step(device_state=(self.hyper, self.step_dev))
+                optimizer.zero_grad()
+        finally:
+            model._arena_override = None
         # capture executed nothing: undo the host-side bookkeeping it did
         optimizer.step_count, model._param_epoch = saved_count, saved_epoch
         self._cache = model._train_cache                   # the images the graph writes: keep them alive

@@ -35,19 +35,22 @@ def run(data_config, model_config, evaluation_config=None, output_dir=None, chec
         LOGGER.info("Splitting dataset, using %s%% for evaluation", split * 100)
         _, dataset = dataset.split(1 - split, seed=seed)
     LOGGER.info("Applying model...")
+    # ONE iteration of the dataset, on every rank: a `shuffle: true` dataset draws a new order per iteration, and the
+    # metrics below pair images with predictions by position
+    images = list(dataset)
     if world > 1:
         # launched with torch.distributed.run: every rank predicts its shard, rank 0 scores
         import torch.distributed as dist
         from dnanet_amd.distributed import predict_batch_sharded
-        predictions = predict_batch_sharded(model, dataset)
+        predictions = predict_batch_sharded(model, images)
         if dist.get_rank() != 0:
             return {}
     else:
-        predictions = model.predict_batch(dataset)
+        predictions = model.predict_batch(images)
     results = {}
     if evaluation_config:
         LOGGER.info("Computing metrics...")
-        results = write_metrics(load_evaluation_config(evaluation_config), dataset, predictions,
+        results = write_metrics(load_evaluation_config(evaluation_config), images, predictions,
                                 os.path.join(output_dir, "metrics.txt"))
     if save_preds:
         LOGGER.info("Saving predictions to JSON...")

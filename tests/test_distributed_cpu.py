@@ -169,3 +169,80 @@ def test_unseeded_split_in_multirank_env_without_group_is_refused(monkeypatch):
     with pytest.raises(RuntimeError):
         ArrayDataset(list(range(10))).split(0.5)
     assert len(ArrayDataset(list(range(10))).split(0.5, seed=3)[0]) == 5      # a seeded split needs no group
+
+
+def _evaluate_shuffled_worker(rank, world, port, out_dir):
+    """evaluate.py on a `shuffle: true` dataset inside a 2-rank job: the metrics pass on rank 0 iterates the
+    dataset on its own -- no collective may hide in __iter__, and predictions must stay paired with their images."""
+    import os
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import evaluate
+    from dnanet_amd.prediction import Prediction
+
+    class Oracle:                                  # stands in for DNANet_UNet (which needs the GPU): predicts the annotation
+        def predict_batch(self, batch):
+            return [Prediction(image=np.asarray(im.annotation.image, np.float32), meta={"original_image_path": im.path})
+                    for im in batch]
+
+        def load(self, _):
+            pass
+
+    evaluate.load_model = lambda cfg: Oracle()
+    cfg = os.path.join(out_dir, "data.yaml")
+    if rank == 0:
+        with open(cfg, "w") as f:
+            f.write("dataset:\n  name: synthetic\n  n: 9\n  rows: 2\n  width: 256\n  seed: 5\n  shuffle: true\n")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    res = evaluate.run(cfg, os.path.join(root, "config/models/unet.yaml"), os.path.join(root, "config/evaluation/segmentation.yaml"),
+                       output_dir=os.path.join(out_dir, f"out{rank}"), save_preds=False)
+    if rank == 0:
+        # paired correctly, a perfect "model" scores 1.0 on every metric; a re-shuffled second iteration would not
+        assert res and all(abs(v - 1.0) < 1e-9 for v in res.values()), res
+        open(os.path.join(out_dir, "ok.txt"), "w").write("ok")
+    else:
+        assert res == {}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_shuffled_dataset_gloo_world2(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_evaluate_shuffled_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok.txt").read_text() == "ok"
+
+
+def _shuffled_iter_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from dnanet_amd.data import ArrayDataset
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = ArrayDataset(list(range(12)), shuffle=True)
+    epochs = [list(ds) for _ in range(2)]                         # both ranks: two "epochs" in the same order
+    extra = [list(ds) for _ in range(3)] if rank == 0 else []     # rank 0 alone goes on iterating: must not wait for anybody
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+        f.write(repr(epochs))
+    assert all(sorted(e) == list(range(12)) for e in epochs + extra)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shuffled_iteration_is_rank_local_gloo_world2(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_shuffled_iter_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = eval((tmp_path / "r0.txt").read_text()), eval((tmp_path / "r1.txt").read_text())
+    assert a == b and a[0] != a[1]                                # same order on both ranks, a new one per epoch
