@@ -595,6 +595,16 @@ def main():
                 out["train_step_global"]["scaling"] = "strong"
             except Exception as exc:      # e.g. out of memory at 1024 profiles per GPU: report, keep the line
                 out["train_step_global"] = {"error": f"{type(exc).__name__}: {exc}"[:300], "per_gpu_batch": per}
+        if distributed and args.dtype != "bf16" and not args.no_legs:
+            # the throughput precision on the same data-parallel path (256 per GPU, and configs[3]'s global batch)
+            out["train_step_bf16"] = train_leg("bf16", args.rows, args.batch, max(5, args.steps // 2), dev, rank, world, True, barrier, reduce_max)
+            if args.global_batch % world == 0:
+                try:
+                    out["train_step_global_bf16"] = train_leg("bf16", args.rows, args.global_batch // world, 3, dev, rank, world, True,
+                                                              barrier, reduce_max)
+                    out["train_step_global_bf16"]["scaling"] = "strong"
+                except Exception as exc:
+                    out["train_step_global_bf16"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if not distributed and not args.no_legs:
             other = "fp32" if args.dtype == "bf16" else "bf16"
             osteps = tsteps if other == "fp32" else max(5, args.steps // 2)

@@ -12,6 +12,7 @@ cache written here is readable by the reference's ``load_from_disk`` and vice ve
 from __future__ import annotations
 
 import json
+import re
 import os
 from pathlib import Path
 from typing import List, Optional, Sequence, Tuple
@@ -38,9 +39,7 @@ def markers_to_json(markers: Sequence[Marker]) -> str:
 def noc_from_rd_file_name(name: str) -> Optional[str]:
     """``get_noc_from_rd_file_name`` (``DNAnet/utils.py:62-70``): '1A2_A01_01.hid' -> '2p'."""
     stem = Path(name).name
-    parts = stem.split(".")[0].split("_")
-    ok = len(parts) >= 3 and len(parts[0]) == 3 and parts[0][0].isdigit() and parts[0][1].isalpha() and parts[0][2].isdigit()
-    return f"{stem[2]}p" if ok else None
+    return f"{stem[2]}p" if re.match(r"\d[ABCDEF]\d", stem[:3]) else None     # the reference's test, the one data.rd_prefix uses
 
 
 def _fixed_block(column, dtype) -> np.ndarray:

@@ -122,7 +122,7 @@ class ArenaAllReducer:
     code runs under gloo on CPU tensors in the tests and under RCCL on the GPU)."""
 
     def __init__(self, flat_grads: torch.Tensor, segments: Sequence[Tuple[str, int, int]], group=None,
-                 min_bucket_elems: int = 1 << 20):
+                 min_bucket_elems: int = 2 << 20):
         self.flat, self.group = flat_grads, group
         self.segments = list(segments)
         self.min_bucket = min_bucket_elems
@@ -191,7 +191,7 @@ def all_reduce_dice_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
 class DataParallelTrainer:
     """One data-parallel training step of ``HipUNet`` on this rank's shard of the global batch."""
 
-    def __init__(self, model, optimizer, group=None, min_bucket_elems: int = 1 << 20, sync_bn: bool = False):
+    def __init__(self, model, optimizer, group=None, min_bucket_elems: int = 2 << 20, sync_bn: bool = False):
         self.model, self.optimizer, self.group = model, optimizer, group
         self.sync_bn = bool(sync_bn)
         model.sync_bn = (lambda t: all_reduce_sum(t, group), dist.get_world_size(group)) if sync_bn else None

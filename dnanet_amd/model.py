@@ -501,9 +501,9 @@ class DNANet_UNet(TrainableModel):
         in_flight: List[tuple] = []
         for s in range(0, len(batch), self.PREDICT_SUB_BATCH):
             sub = batch[s:s + self.PREDICT_SUB_BATCH]
-            in_flight.append((sub, self._predict_launch(sub)))
-            if len(in_flight) > 2:
+            if len(in_flight) >= 2:                   # at most two stages in flight: finish the oldest before queuing a third
                 predictions += self._predict_finish(*in_flight.pop(0))
+            in_flight.append((sub, self._predict_launch(sub)))
         while in_flight:
             predictions += self._predict_finish(*in_flight.pop(0))
         return predictions
@@ -567,7 +567,7 @@ class DNANet_UNet(TrainableModel):
         else:
             truth = truth.astype(np.int8, copy=False)            # uint8 values >= 128 wrap to negatives: still "other"
         truth = np.ascontiguousarray(np.transpose(truth, (0, 3, 1, 2)))
-        truth_dev = torch.from_numpy(truth).to(probs.device, non_blocking=True)
+        truth_dev = torch.from_numpy(truth).to(probs.device)     # pageable temporary: a synchronous copy (it is 20 kB per profile)
         counts = torch.empty((len(batch), 7), dtype=torch.int32, device=probs.device)
         hip.check(hip.lib.dn_pixel_confusion(hip.ptr(probs), hip.ptr(truth_dev), len(batch), probs[0].numel(), 0.5, 0.5,
                                              hip.ptr(counts), hip.stream_ptr()))

@@ -13,18 +13,13 @@ for the integer RFU arrays it is applied to, that equals the exact shift used he
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import numpy as np
 
 SIZE_STANDARD_BPS = np.array([65, 80, 100, 120, 140, 160, 180, 200, 225, 250, 275, 300, 325, 350, 375, 400, 425, 450, 475])
 BASE_PAIR_START, BASE_PAIR_END = 65, 475
 RESCALE_SIZE = 4096
-
-
-def basepair_to_pixel(scaler: np.ndarray, bp: float) -> float:
-    """``utils.py:14-18``"""
-    return float(np.argmin(np.abs(scaler - bp), axis=1)[0])
 
 
 def _shift(array: np.ndarray, by: int) -> np.ndarray:
@@ -44,39 +39,6 @@ def find_peaks_above_threshold(array: np.ndarray, threshold: int) -> np.ndarray:
     array = np.asarray(array)
     prev, nxt = _shift(array, 1), _shift(array, -1)
     return np.where((((array >= prev) & (array > nxt)) | ((array > prev) & (array >= nxt))) & (array >= threshold))[0]
-
-
-def find_peak_boundary(array: np.ndarray, idx: int, threshold: int) -> Tuple[int, int]:
-    """``utils.py:130-154``"""
-    array = np.asarray(array).flatten()
-    below = array < threshold
-    left = np.flatnonzero(below[:idx])
-    right = np.flatnonzero(below[idx:])
-    start = int(left[-1]) + 1 if left.size else 0
-    end = int(right[0]) + idx - 1 if right.size else len(array) - 1
-    return start, end
-
-
-def find_peak_near_idx(array: np.ndarray, idx: int) -> np.ndarray:
-    """``utils.py:157-167``: nearest peak at least as high as ``array[idx]``; the first one on equal distance."""
-    peaks = find_peaks_above_threshold(array, array[idx])
-    return peaks[np.abs(peaks - idx).argmin(), np.newaxis]
-
-
-def find_peak_idx_near_or_in_range(array: np.ndarray, index_range: np.ndarray, threshold: int) -> np.ndarray:
-    """``utils.py:170-193``"""
-    array = np.asarray(array)
-    values = array[index_range].flatten()
-    steps = np.diff(values)
-    if np.all(steps > 0):
-        peak_idx = find_peak_near_idx(array.flatten(), index_range[-1])
-    elif np.all(steps < 0):
-        peak_idx = find_peak_near_idx(array.flatten(), index_range[0])
-    else:
-        peak_idx = find_peaks_above_threshold(values, threshold) + index_range[0]
-        if peak_idx.size > 1:
-            peak_idx = peak_idx[np.argmax(array[peak_idx].flatten()), np.newaxis]
-    return peak_idx if peak_idx.size > 0 and array[peak_idx] >= threshold else np.array([])
 
 
 def extract_ss_peaks(array: np.ndarray) -> np.ndarray:

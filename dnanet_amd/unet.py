@@ -81,6 +81,7 @@ class HipUNet(ParameterTree):
         # units on the main stream.  DN_TUNE_NO_WGRAD_STREAM=1 keeps everything on one stream (A/B switch).
         self.overlap_wgrad = self.flat_params.is_cuda and not os.environ.get("DN_TUNE_NO_WGRAD_STREAM")
         self._wgrad_stream = None
+        self.two_stream_max_pixels = 20_000_000       # N*H*W above which backward stays on one stream (see _side)
         # Device memory of the passes: one StepArena per (kind of pass, batch shape), allocated by the first pass at that
         # shape and reused by every later one (no allocator calls in steady state).  Least recently used arenas are
         # dropped when the total passes ``arena_budget_bytes``.
@@ -666,7 +667,7 @@ class HipUNet(ParameterTree):
         # measured (bf16, 6 x 4096): two streams win 3 % at 256 profiles, 5 % at 512, lose nothing at 768 -- and lose 40 % at
         # 1024, where the concurrent kernels' working sets (84 GiB live) evict each other
         S = self._saved
-        if S is not None and S["n"] * S["h"] * S["w"] > 20_000_000:
+        if S is not None and S["n"] * S["h"] * S["w"] > self.two_stream_max_pixels:
             return None
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)

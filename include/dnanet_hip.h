@@ -164,7 +164,10 @@ int dn_bn_train_forward(dn_tensor y, dn_tensor a, int N, int H, int W, const flo
  * reduction partials live in a 2.02 MiB array inside the library (one copy per GPU, held until the process ends) instead
  * of a caller-provided workspace; the call itself allocates nothing.  Limit: y.channels <= DN_NOALLOC_MAX_CHANNELS (512,
  * the widest layer of the shipped net), otherwise DN_STATUS_BAD_ARGUMENT.  All calls on one GPU share that array: calls
- * that overlap on one GPU (different streams or threads) race; calls on one stream are ordered and safe. */
+ * that overlap on one GPU (different streams or threads) race; calls on one stream are ordered and safe.  The FIRST call
+ * on a device looks up that device's address of the array (hipGetSymbolAddress under a mutex: a lookup, not an
+ * allocation): make one call per device before a stream capture starts, and only then capture
+ * (tests/test_zz_no_alloc.py does exactly that). */
 #define DN_NOALLOC_MAX_CHANNELS 512
 int dn_bn_train_forward_noalloc(dn_tensor y, dn_tensor a, int N, int H, int W, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,

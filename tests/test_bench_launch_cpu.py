@@ -42,3 +42,27 @@ def test_world_size_mismatch_is_refused():
     proc = _run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert proc.returncode != 0
     assert "refusing" in proc.stderr and '{"metric"' not in proc.stdout
+
+
+def test_gpus_4_and_8_without_launcher_spawn_that_many_ranks():
+    """The sizes the driver's scaling run uses (N = 1, 2, 4, 8): rendezvous, rank set and the max-over-ranks timing."""
+    for n in (4, 8):
+        proc = _run(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--dry-run"], timeout=600)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        line = _line(proc)
+        assert line["n_gpus"] == n and line["ranks_seen"] == list(range(n)) and line["world_size_seen_by_rank0"] == n
+
+
+def test_launcher_started_ranks_are_accepted_when_world_size_matches():
+    """The driver's own form: torch.distributed.run starts the ranks, bench.py reads RANK / WORLD_SIZE from the environment."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run"],
+                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = _line(proc)
+    assert line["n_gpus"] == 4 and line["ranks_seen"] == [0, 1, 2, 3]

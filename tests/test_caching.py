@@ -109,3 +109,14 @@ def test_reference_data_config_name_hid_reads_the_cache(tmp_path):
     (tmp_path / "raw.yaml").write_text(yaml.safe_dump(cfg))
     with pytest.raises(NotImplementedError, match="arrow cache"):
         load_dataset(str(tmp_path / "raw.yaml"))
+
+
+def test_noc_from_rd_file_name_follows_the_reference_regex():
+    """``get_noc_from_rd_file_name`` (``DNAnet/utils.py:35-40,62-70``): the first three characters must look like '1A2' with a
+    mixture letter A-F; nothing else about the name matters."""
+    from dnanet_amd.caching import noc_from_rd_file_name
+    assert noc_from_rd_file_name("1A2_A01_01.hid") == "2p"
+    assert noc_from_rd_file_name("1A2.hid") == "2p"                # no '_' parts needed
+    assert noc_from_rd_file_name("/some/dir/3F5_H12_07.hid") == "5p"
+    assert noc_from_rd_file_name("1G2_A01_01.hid") is None          # G is not a mixture letter of the R&D set
+    assert noc_from_rd_file_name("Ladder_A01.hid") is None

@@ -246,3 +246,57 @@ def test_shuffled_iteration_is_rank_local_gloo_world2(tmp_path):
     mp.spawn(_shuffled_iter_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a, b = eval((tmp_path / "r0.txt").read_text()), eval((tmp_path / "r1.txt").read_text())
     assert a == b and a[0] != a[1]                                # same order on both ranks, a new one per epoch
+
+
+def _shipped_arena_worker(rank, world, port, out_dir):
+    """ArenaAllReducer over the SHIPPED net's gradient arena (12.1 M floats, segments from 33 floats (head) to 5.9 M
+    (bottleneck)) with the production bucket floor, four ranks."""
+    import json
+    import os
+    import torch
+    import torch.distributed as dist
+    from dnanet_amd.distributed import ArenaAllReducer, module_segments
+    from dnanet_amd.params import ParameterTree
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tree = ParameterTree(4, (3, 5), 32, "cpu")
+    segs = module_segments(tree.offsets, 4, tree.flat_grads.numel())
+    tree.flat_grads.fill_(float(rank + 1))
+    red = ArenaAllReducer(tree.flat_grads, segs)                 # min_bucket_elems: the default DataParallelTrainer uses
+    order = []
+    for name, _, _ in segs:                                      # backward's order: head, decoders 3..0, bottleneck, encoders 3..0
+        red.segment_done(name)
+        order.append((name, list(red.launched)))
+    buckets = red.finish()
+    ok = bool((tree.flat_grads == float(sum(range(1, world + 1)))).all())
+    if rank == 0:
+        with open(os.path.join(out_dir, "buckets.json"), "w") as f:
+            json.dump({"buckets": buckets, "ok": ok, "segments": [(n, a, b) for n, a, b in segs], "order": order}, f)
+    assert ok
+    dist.destroy_process_group()
+
+
+def test_arena_all_reduce_shipped_arena_gloo_world4(tmp_path):
+    """3-4 buckets in reverse (backward) order; every element reduced exactly once; uneven segments."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_shipped_arena_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    rec = json.loads((tmp_path / "buckets.json").read_text())
+    buckets, segs = rec["buckets"], rec["segments"]
+    assert rec["ok"] and 3 <= len(buckets) <= 4, buckets
+    total = max(b for _, _, b in segs)
+    spans = sorted(map(tuple, buckets))
+    assert spans[0][0] == 0 and spans[-1][1] == total and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    assert all(b - a >= 2 << 20 for a, b in buckets[:-1])        # only the last flush may be smaller than the floor
+    # launch order follows backward: the first bucket holds the head and the decoders' end of the arena, the last one encoders.0
+    by_name = {n: (a, b) for n, a, b in segs}
+    assert buckets[0][0] <= by_name["head"][0] < buckets[0][1]
+    assert buckets[-1][0] <= by_name["encoders.0"][0] < buckets[-1][1]
+    # a bucket is launched as soon as its segments are complete, not at the end: by the time the bottleneck is reported at
+    # least one reduction is already in flight
+    launched_at = {name: len(l) for name, l in rec["order"]}
+    assert launched_at["bottleneck"] >= 1 and launched_at["encoders.0"] <= len(buckets)

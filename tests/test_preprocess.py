@@ -22,20 +22,6 @@ def test_find_peaks_above_threshold_known_answers(array, result):       # refere
     assert np.array_equal(P.find_peaks_above_threshold(np.array(array), 200), np.array(result))
 
 
-def test_peak_helpers_known_answers():                                  # reference tests/data/test_utils.py:29-65
-    assert P.find_peak_boundary(np.array([110, 90, 101, 103, 110, 103, 90, 101]), 4, threshold=100) == (2, 5)
-    assert P.find_peak_boundary(np.array([90, 90, 90, 90, 110, 90, 90, 90]), 4, threshold=100) == (4, 4)
-    assert P.find_peak_boundary(np.array([110, 100, 101, 103, 110, 103, 100, 101]), 4, threshold=100) == (0, 7)
-    a = np.array([100, 101, 110, 103, 102, 101, 120, 101])
-    assert P.find_peak_near_idx(a, 1) == [2] and P.find_peak_near_idx(a, 7) == [6] and P.find_peak_near_idx(a, 4) == [2]
-    assert np.array_equal(P.find_peak_idx_near_or_in_range(a, np.array([1, 2, 3]), threshold=100), [2])
-    assert np.array_equal(P.find_peak_idx_near_or_in_range(a, np.array([0, 1]), threshold=100), [2])
-    b = np.array([100, 101, 110, 103, 202, 101, 120, 101])
-    assert np.array_equal(P.find_peak_idx_near_or_in_range(b, np.arange(7), threshold=100), [4])
-    c = np.array([80, 81, 90, 83, 82, 81, 90, 81])
-    assert np.array_equal(P.find_peak_idx_near_or_in_range(c, np.array([1, 2, 3]), threshold=100), [])
-
-
 def test_basepair_interpolator_known_answers():                         # reference tests/data/test_utils.py:82-110
     assert np.array_equal(P.basepair_interpolator([0, 3, 6], [1, 7, 13])(np.arange(6)), [1., 3., 5., 7., 9., 11.])
     ex = P.basepair_interpolator([2, 3], [12, 13], extrapolate=True)
@@ -58,7 +44,6 @@ def test_restatement_equals_reference_fixture(name):
     assert np.array_equal(P.rescale_dye(bps), g["idx"])
     data, scaler = P.rescale_profile(profile)
     assert data.shape == (6, 4096, 1) and np.array_equal(data, g["data"]) and np.array_equal(scaler, g["scaler"])
-    assert P.basepair_to_pixel(scaler[None], 0) == 0.0 and P.basepair_to_pixel(scaler[None], 1000) == 4095.0
 
 
 @pytest.mark.gpu

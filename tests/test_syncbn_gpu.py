@@ -56,6 +56,44 @@ def test_sync_bn_world1_is_bitwise_the_plain_step(gpu_device):
         dist.destroy_process_group()
 
 
+def test_data_parallel_step_on_one_stream_equals_two_streams(gpu_device):
+    """Above ``two_stream_max_pixels`` (1024 six-dye profiles per GPU: configs[3] on 2 GPUs) backward keeps the weight gradients
+    on the main stream and the bucket hooks are called in stream order right behind them.  Forced here on a small net, through
+    the RCCL group of one rank: the step must be bitwise the two-stream step and the plain step, with the same buckets."""
+    import torch.distributed as dist
+    from dnanet_amd.distributed import DataParallelTrainer
+    from dnanet_amd.unet import HipAdam, HipUNet
+    g = load_golden("g_d3_k35_f8_h5_w128")
+    x, t = torch.from_numpy(g["x"]).to(gpu_device), torch.from_numpy(g["t"]).to(gpu_device)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        out = []
+        for limit, parallel in ((20_000_000, True), (0, True), (20_000_000, False)):
+            m = HipUNet(3, (3, 5), 8, gpu_device, dtype="fp32")
+            m.load_state_dict(g["sd0"])
+            m.train()
+            m.two_stream_max_pixels = limit
+            opt = HipAdam(m, lr=1e-3, weight_decay=5e-4)
+            tr = DataParallelTrainer(m, opt, min_bucket_elems=10000) if parallel else None
+            calls = []
+            if tr is not None:
+                inner = tr.reducer.segment_done
+                tr.reducer.segment_done = lambda name: (calls.append((name, torch.cuda.current_stream() == m._wgrad_stream)),
+                                                        inner(name))[1]
+            loss = _steps(m, opt, x, t, tr)
+            out.append((m.flat_params.clone(), m.flat_stats.clone(), loss, tr.reducer.last_buckets if tr else None, calls))
+        two, one, plain = out
+        assert [c[0] for c in one[4][:8]] == ["head", "decoders.2", "decoders.1", "decoders.0", "bottleneck", "encoders.2",
+                                               "encoders.1", "encoders.0"]
+        assert all(on_side for _, on_side in two[4]) and not any(on_side for _, on_side in one[4])
+        assert one[3] == two[3] and len(one[3]) >= 2
+        for a, b in ((one, two), (one, plain)):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+    finally:
+        dist.destroy_process_group()
+
+
 def _two_rank_worker(rank, world, port, sync_bn, out_path):
     import torch.distributed as dist
     from conftest import load_golden as lg
