@@ -49,36 +49,56 @@ def test_fit_348_profiles_batch16_shipped_net_vs_oracle_loop(gpu_device, monkeyp
     assert len(losses) == 21 and len(replays) == 20 and set(replays) == {(16, 1, 5, 4096)}     # 1 eager warm-up + 20 replays
     got_losses = [float(l) for l in losses]
 
-    # the oracle: the reference's loop on the CPU (21 steps, ~1.5 s each on the box's 16 cores)
+    # The oracle: the reference's loop on the CPU in fp32 (the reference's arithmetic), run here (21 steps, ~1 s each on the
+    # box's 16 cores).  Two correct fp32 implementations drift apart through 21 Adam steps -- an element whose gradient is
+    # rounding noise moves by +-lr per step in either -- so "equal" needs a yardstick: tests/golden/config2_fit_yardstick.npz
+    # (make_config2_yardstick.py) holds the same loop run in fp64 -- its loss trajectory and running statistics -- and, per
+    # tensor, how far torch's own fp32 run ends up from it.  The HIP fp32 path must be as close to the fp64 losses /
+    # statistics as torch's fp32 is, and as close to torch's fp32 parameters as two independent fp32 runs can be expected
+    # to be (each e away from fp64 => up to 2e from each other).
+    import os
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    y = np.load(os.path.join(GOLDEN_DIR, "config2_fit_yardstick.npz"), allow_pickle=False)
+    assert list(y["config"]) == [3, 11, 16, 348, 21]
+    images = list(ds)
     sd = OrderedDict((k, v.clone()) for k, v in sd0.items())
     state = O.AdamState(O.trainable_keys(sd), sd)
-    images = list(ds)
-    want_losses = []
-    for s in range(len(images) // 16):
+    loss32 = []
+    for s in range(len(images) // 16):                             # 21 steps; profiles 336..347 are never used
         batch = images[16 * s:16 * s + 16]
         x = torch.stack([torch.from_numpy(im.data.astype("float32")).permute(2, 0, 1) for im in batch])
         t = torch.stack([torch.from_numpy(im.annotation.image).permute(2, 0, 1) for im in batch])
         loss, _, _ = O.train_step(sd, x, t, state, O.exponential_lr(1e-4, 0), 5e-4)
-        want_losses.append(float(loss))
-    worst = max(abs(a - b) for a, b in zip(got_losses, want_losses))
-    print("loss trajectory: worst |delta|", worst, "first/last", got_losses[0], got_losses[-1], want_losses[-1])
-    assert worst < 2e-5, (got_losses, want_losses)
-    assert abs(epoch_losses[0] - sum(want_losses) / 21) < 2e-5
+        loss32.append(float(loss))
+    loss64 = [float(v) for v in y["loss64"]]
+    dev_hip = max(abs(a - b) for a, b in zip(got_losses, loss64))
+    dev_cpu = max(max(abs(a - b) for a, b in zip(loss32, loss64)), float(np.abs(y["loss32"] - y["loss64"]).max()))
+    print(f"loss trajectory vs fp64: hip {dev_hip:.2e}, torch fp32 {dev_cpu:.2e}; hip vs torch fp32 "
+          f"{max(abs(a - b) for a, b in zip(got_losses, loss32)):.2e}; first / last {got_losses[0]:.6f} / {got_losses[-1]:.6f}")
+    assert abs(got_losses[0] - loss32[0]) < 2e-6                    # the first step: no drift yet
+    assert dev_hip < 2 * dev_cpu + 2e-5, (dev_hip, dev_cpu)
+    assert abs(epoch_losses[0] - sum(loss64) / 21) < 2 * dev_cpu + 2e-5
 
     got = model._model.state_dict()
-    frac_worst = 0.0
     for k, v in sd.items():
         if v.dtype == torch.int64:
             assert int(got[k]) == int(v) == 21, k                        # num_batches_tracked: 21 steps, no 22nd for the tail
-        elif "running" in k:
-            assert torch.allclose(got[k].cpu(), v, rtol=1e-4, atol=1e-5), k
-        else:
-            # Adam divides by sqrt(v): an element whose gradient is rounding noise moves by +-lr per step in either
-            # implementation -- bound the outliers by the distance 21 steps can cover, require the bulk to agree tightly
-            d = (got[k].cpu() - v).abs()
-            assert float(d.max()) <= 2.5 * 1e-4 * 21, (k, float(d.max()))
-            frac = float((d > 2e-5 + 2e-3 * v.abs()).float().mean())
-            frac_worst = max(frac_worst, frac)
-            assert frac < 1e-2, (k, frac)
-    print("worst share of elements off by more than 2e-5 + 2e-3 |v|:", frac_worst)
+    worst = {"stats": ("", 0.0, 0.0), "update": ("", 0.0, 0.0)}
+    for k, e_cpu in zip(y["stats_keys"], y["stats_err_fp32_vs_fp64"]):
+        k, v64 = str(k), torch.from_numpy(y["stats64/" + str(k)])
+        e_hip = float((got[k].cpu().double() - v64).abs().max() / v64.abs().max())
+        if e_hip > worst["stats"][1]:
+            worst["stats"] = (k, e_hip, float(e_cpu))
+        assert e_hip < 2 * float(e_cpu) + 0.02, (k, e_hip, float(e_cpu))
+    for k, e_cpu in zip(y["update_keys"], y["update_err_fp32_vs_fp64"]):
+        k = str(k)
+        hip_v, cpu_v = got[k].cpu().double(), sd[k].double()
+        assert float((hip_v - cpu_v).abs().max()) <= 2.5 * 1e-4 * 21, k          # no element further than 21 steps can go
+        # the UPDATE of 21 steps (parameters after - before), hip against torch fp32, relative to the fp64 update's norm
+        e_hip = float((hip_v - cpu_v).flatten().norm() / float(y["update_norm64/" + k]))
+        if e_hip > worst["update"][1]:
+            worst["update"] = (k, e_hip, float(e_cpu))
+        assert e_hip < 2 * float(e_cpu) + 0.02, (k, e_hip, float(e_cpu))
+    print("worst (tensor, hip error, torch fp32's distance from fp64):", worst)
     assert model._model.arena_stats()["allocations"] > 0
