@@ -26,5 +26,8 @@ int conv_wgrad_run_bf16_k11(const WgradParams& p, long slab_bytes, int* nslab, h
 int conv_wgrad_run_f32_k35(const WgradParams& p, long slab_bytes, int* nslab, hipStream_t s);
 int conv_wgrad_run_f32_k13(const WgradParams& p, long slab_bytes, int* nslab, hipStream_t s);
 int conv_wgrad_run_f32_k11(const WgradParams& p, long slab_bytes, int* nslab, hipStream_t s);
+#include "convt_wgrad.h"
+int convt_wgrad_run_bf16(ConvtWgradParams& p, int cout, long slab_bytes, int* nslab, hipStream_t s);
+int convt_wgrad_run_f32(ConvtWgradParams& p, int cout, long slab_bytes, int* nslab, hipStream_t s);
 int conv_first_mfma_run(const float* x, const float* wf, const ConvParams& p, int kh, int kw, int dtype, hipStream_t s);
 int conv_first_row_tile(int H);

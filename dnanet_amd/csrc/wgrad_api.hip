@@ -80,6 +80,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_conv_kernel(const float* __r
   }
 }
 
+// ConvTranspose2d form for MANY slabs of a small tensor (convt_wgrad.h: up to 512 splits of a 64 x 64 .. 512 x 512 output):
+// a block sums 16 consecutive slab elements over 16 slab lanes (slab b goes to lane b % 16, four independent chains per
+// lane), then the lanes are added in a fixed order -- 256 x more threads per element than one chain per element, which left
+// the 64 -> 32 layer's reduction (16 blocks walking 2048 slabs) longer than its GEMM.  Bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_convt_kernel(const float* __restrict__ slab, int nslab, int co_pad, int ci_pad,
+                                                                 float* dw, int Cout, int Cin, int gsize) {
+  __shared__ float part[16][17];
+  const long per = (long)co_pad * ci_pad;
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < per) {
+    int b = sl;
+    for (; b + 48 < nslab; b += 64) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[k] += slab[(long)(b + 16 * k) * per + i];
+    }
+    for (; b < nslab; b += 16) c[0] += slab[(long)b * per + i];
+  }
+  part[sl][e] = (c[0] + c[1]) + (c[2] + c[3]);
+  __syncthreads();
+  if (threadIdx.x < 16 && i < per) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += part[k][e];
+    const int ci = (int)(i % ci_pad), row = (int)(i / ci_pad);
+    const int k = row / gsize, co = row % gsize;
+    if (k < 2 && co < Cout && ci < Cin) dw[((long)ci * Cout + co) * 2 + k] = s;
+  }
+}
+
 int run_wgrad(WgradParams& p, long ws_bytes, int kh, int kw, int dtype, int* nslab, hipStream_t s) {
   if (dtype == DN_BF16) {
     if (kh == 3 && kw == 5) return conv_wgrad_run_bf16_k35(p, ws_bytes, nslab, s);
@@ -140,6 +171,24 @@ int dn_conv_transpose_1x2_wgrad(dn_tensor dy, dn_tensor x, float* dw, void* work
   DN_CHECK_ARG(N > 0 && H > 0 && Win > 0, "dn_conv_transpose_1x2_wgrad: bad shape");
   DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_transpose_1x2_wgrad: bad dtype %d", dtype);
   const int epr = dtype == DN_BF16 ? 16 : 8;
+  // the large-tile GEMM (convt_wgrad.h) when the image is whole strips of pixels (every level of a U-Net on 4096 scans)
+  if ((H * Win) % 64 == 0 && !dn_tune().no_convt_gemm) {
+    ConvtWgradParams q{};
+    q.dy = dy.base; q.dy_pt = dy.planes_total; q.dy_p0 = dy.plane0; q.dy_nplanes = dn_planes(dy.channels, dtype);
+    q.x = x.base; q.x_pt = x.planes_total; q.x_p0 = x.plane0; q.x_nplanes = dn_planes(x.channels, dtype);
+    DN_CHECK_ARG(dy.plane0 >= 0 && x.plane0 >= 0 && dy.plane0 + q.dy_nplanes <= dy.planes_total && x.plane0 + q.x_nplanes <= x.planes_total,
+                 "dn_conv_transpose_1x2_wgrad: planes outside buffer");
+    q.slab = (float*)workspace; q.N = N; q.HW = H * Win;
+    int nslab = 0;
+    const int rc = dtype == DN_BF16 ? convt_wgrad_run_bf16(q, dy.channels, workspace_bytes, &nslab, (hipStream_t)stream)
+                                    : convt_wgrad_run_f32(q, dy.channels, workspace_bytes, &nslab, (hipStream_t)stream);
+    if (rc) return rc;
+    const long per = (long)2 * q.gsize * q.ci_pad;
+    hipLaunchKernelGGL(wgrad_reduce_convt_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, nslab, 2 * q.gsize, q.ci_pad, dw, dy.channels, x.channels, q.gsize);
+    DN_LAUNCH_CHECK();
+    return DN_OK;
+  }
   const int co_t = dtype == DN_BF16 ? 64 : 32;
   const int gsize = tile_pad(dy.channels, co_t);
   WgradParams p{};

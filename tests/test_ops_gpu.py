@@ -458,6 +458,37 @@ def test_conv_transpose_wgrad_and_bias(gpu_device, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(3, 64, 32, 5, 128), (2, 128, 64, 6, 64), (2, 512, 256, 4, 32), (2, 272, 136, 4, 64),
+                                  (1, 40, 24, 8, 64), (9, 256, 128, 6, 64), (5, 32, 16, 2, 2048)])
+def test_conv_transpose_wgrad_large_tile_gemm(gpu_device, dtype, case):
+    """The split-K GEMM of convt_wgrad.h (taken when H * Win is whole 64-pixel strips): every tile size (64, 128, 256 rows /
+    columns), partially filled tiles, more splits than strips, operands that are plane ranges inside wider buffers -- exact on
+    small-integer data against autograd, and bitwise equal to the 1x1 kernel it replaces (DN_TUNE switch not needed: the
+    sums are integers)."""
+    hip = _hip()
+    n, cin, cout, h, win = case
+    g = torch.Generator().manual_seed(7)
+    x = _rand((n, cin, h, win), g, True)
+    dy = _rand((n, cout, h, 2 * win), g, True)
+    wt = torch.zeros(cin, cout, 1, 2, requires_grad=True)
+    F.conv_transpose2d(x, wt, None, stride=(1, 2)).backward(dy)
+    # x sits behind 3 foreign planes, dY in the first half of a concat-gradient buffer (as HipUNet.backward passes them)
+    px, py = hip.planes(cin, dtype), hip.planes(cout, dtype)
+    xb = hip.PlaneBuffer(n, px + 3, h, win, dtype, gpu_device)
+    xb.data.fill_(3.0)
+    xb.data[:, 3:].copy_(hip.PlaneBuffer.from_nchw(x.to(gpu_device), dtype).data)
+    dyb = hip.PlaneBuffer(n, 2 * py, h, 2 * win, dtype, gpu_device)
+    dyb.data.fill_(5.0)
+    dyb.data[:, :py].copy_(hip.PlaneBuffer.from_nchw(dy.to(gpu_device), dtype).data)
+    ws = torch.empty(160 << 20, dtype=torch.uint8, device=gpu_device)
+    dw = torch.full((cin, cout, 1, 2), 7.0, device=gpu_device)
+    hip.check(hip.lib.dn_conv_transpose_1x2_wgrad(dyb.ref(cout, 0), xb.ref(cin, 3), hip.ptr(dw), hip.ptr(ws), ws.numel(), n, h, win,
+                                                  dtype, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dw.cpu(), wt.grad)
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 def test_batchnorm_train_forward_backward(gpu_device, dtype):
     hip = _hip()
     n, c, h, w = 3, 24, 5, 64

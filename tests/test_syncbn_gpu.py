@@ -89,7 +89,9 @@ def test_data_parallel_step_on_one_stream_equals_two_streams(gpu_device):
         assert all(on_side for _, on_side in two[4]) and not any(on_side for _, on_side in one[4])
         assert one[3] == two[3] and len(one[3]) >= 2
         for a, b in ((one, two), (one, plain)):
-            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # (the trainer forms the loss from the all-reduced sums with torch arithmetic, the plain step inside the Dice kernel)
+        assert one[2] == two[2] and abs(one[2] - plain[2]) < 1e-6
     finally:
         dist.destroy_process_group()
 
