@@ -70,7 +70,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   constexpr int A_PS = A_RAW + (TR::PHASE - A_RAW % TR::BANKW + TR::BANKW) % TR::BANKW;      // planes of one read hit distinct banks
   constexpr int DY_BYTES = (CO_PL * DY_PS + 1023) / 1024 * 1024, A_BYTES = CI_PL * A_PS;   // dY region ends on a 1-KB piece boundary
   constexpr bool KSPLIT = TAPS < 4;                         // waves split K steps instead of taps
-  constexpr int WT = KSPLIT ? TAPS : (TAPS + 3) / 4;        // taps per wave
+  // COL4 (fp32 3x5): wave w owns kernel column w (KH accumulators) in every K step, and the KH taps of the LAST column are
+  // shared by K: in each group of four K steps, wave w multiplies them for step w (KH more accumulators, partial sums that
+  // the epilogue adds up through LDS in a fixed order).  15 MFMAs per wave and four K steps instead of 16 / 16 / 16 / 12:
+  // no wave waits for the others.  fp32 has the registers for it (6 accumulators = 96); the bf16 tile (two output-channel
+  // groups per tap) does not, and keeps the 4/4/4/3 map below.
+  constexpr bool COL4 = sizeof(T) == 4 && KH == 3 && KW == 5 && (SW / TR::KSTEP) % 4 == 0;
+  constexpr int WT = KSPLIT ? TAPS : (COL4 ? 2 * KH : (TAPS + 3) / 4);        // accumulator sets (taps) per wave
   constexpr int NK = SW / KSTEP;                            // K steps per row of the strip
   static_assert(!KSPLIT || (HT == 1 && NK % 4 == 0), "K steps must split over 4 waves");
   constexpr int ST_ITERS = (DY_BYTES + A_BYTES + 4095) / 4096;
@@ -122,8 +128,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   // 3x5: accumulator i < 3 of wave w is tap (kernel row i, column w) -- the kernel row of an accumulator is a compile-time
   // constant, which lets the products with a zero halo row be left out below -- and accumulator 3 is column 4 of kernel
   // row w (waves 0..2; wave 3 has none).
-  static_assert(KSPLIT || (KH == 3 && KW == 5 && WT == 4), "tap-to-wave map is written for 3x5");
+  static_assert(KSPLIT || (KH == 3 && KW == 5 && (WT == 4 || COL4)), "tap-to-wave map is written for 3x5");
   auto tap_of = [&](int i) {
+    if (COL4) return i < KH ? i * KW + wave : (i - KH) * KW + KW - 1;
     return KSPLIT ? i : (i < KH ? i * KW + wave : min(wave, KH - 1) * KW + KW - 1);
   };
   int tap_off[WT];
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int dh = tap / KW, dw = tap - dh * KW;
     tap_off[i] = __builtin_amdgcn_readfirstlane((dh * QW + dw) * 32);
   }
-  const bool last_tap_real = KSPLIT || wave < KH;                   // wave-uniform (same waves under either map)
+  const bool last_tap_real = KSPLIT || COL4 || wave < KH;           // wave-uniform (same waves under either map)
   (void)last_tap_real;
   // bf16 fragment addressing (ds_read_b64_tr_b16): 16-lane group g reads pixels 8*(g>>1).. of plane (g&1)
   const int gpl_c = (lane >> 4) & 1;
@@ -233,8 +240,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   auto strips = [&](auto top_c, auto bot_c) {
   constexpr bool TOP = decltype(top_c)::value, BOT = decltype(bot_c)::value;
   auto dead = [&](int i, int r) -> bool {       // (accumulator, strip row) sees only a zero row of A
-    if (KSPLIT || i >= KH) return false;        // accumulator 3's kernel row depends on the wave
-    return (TOP && r == 0 && i == 0) || (BOT && r == HT - 1 && i == KH - 1);
+    if (KSPLIT || (!COL4 && i >= KH)) return false;        // 4/4/4/3 map: accumulator 3's kernel row depends on the wave
+    const int krow = i % KH;                               // COL4: accumulators KH.. are the last column's rows
+    return (TOP && r == 0 && krow == 0) || (BOT && r == HT - 1 && krow == KH - 1);
   };
   for (int strip = split; strip < p.nstrips; strip += p.nsplit, buf = buf + 1 == NBUF ? 0 : buf + 1) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ST_ITERS) : "memory");
@@ -365,33 +373,71 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         }
       }
     } else {
-      const int foff = (l31 & 7) * 4;                    // channel inside its plane
-      const int fpl = l31 >> 3;
+      // fp32: one value per lane and operand (v_mfma_f32_32x32x2_f32, K step = 2 pixels): lane l31 holds channel l31 & 7 of
+      // plane l31 >> 3 at pixel 2 * ks + half.  The K steps of a strip are fully unrolled and register double buffered --
+      // the fragments of step it + 1 are read while the MFMAs of step it run -- and the loop is ONE basic block: the wave
+      // with three real taps multiplies its repeated tap into the accumulator that is never stored instead of branching
+      // around it.  (The plain loop -- read, wait, multiply, a branch around the odd tap -- left a K step's LDS latency
+      // exposed twice: 0.76 of the fp32 matrix peak on every layer; the fp32 pipe is not power limited, the spare MFMA of
+      // one wave in four costs no time.)
+      constexpr int NIT = KSPLIT ? NK / 4 : HT * NK;
+      constexpr int WM = COL4 ? KH : WT;                    // accumulators multiplied in every K step
+      const unsigned char* dbase0 = smem + (l31 >> 3) * DY_PS + half * 32 + (l31 & 7) * 4;
+      const unsigned char* abase0 = smem + DY_BYTES + (l31 >> 3) * A_PS + half * 32 + (l31 & 7) * 4;
+      const unsigned char* abase[WT];
 #pragma unroll
-      for (int r = 0; r < HT; ++r) {
-#pragma unroll 4
-        for (int ks0 = 0; ks0 < NK; ks0 += (KSPLIT ? 4 : 1)) {
-          const int ks = KSPLIT ? ks0 + wave : ks0;
-          const int px = ks * 2 + half;
-          float af[NCOG];
+      for (int i = 0; i < WT; ++i) abase[i] = abase0 + tap_off[i] + (COL4 && i >= KH ? wave * 64 : 0);   // the shared column: my K step of four
+      const unsigned char* dbase4 = dbase0 + wave * 64;
+      (void)dbase4;
+      auto load_frags = [&](int it, float (&af)[NCOG], float (&bf)[WM][NCIG]) {
+        const int r = KSPLIT ? 0 : it / NK;
+        const int ks = KSPLIT ? it * 4 + wave : it - r * NK;
 #pragma unroll
-          for (int cg = 0; cg < NCOG; ++cg)
-            af[cg] = *(const float*)(smem + (cg * PLG + fpl) * DY_PS + (r * SW + px) * 32 + foff);
-          float bf[WT][NCIG];
+        for (int cg = 0; cg < NCOG; ++cg) af[cg] = *(const float*)(dbase0 + cg * PLG * DY_PS + (r * SW + ks * 2) * 32);
 #pragma unroll
-          for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WM; ++i) {
+          if (dead(i, r)) continue;                          // compile time: nobody multiplies these
 #pragma unroll
-            for (int cg = 0; cg < NCIG; ++cg)
-              bf[i][cg] = *(const float*)(smem + DY_BYTES + (cg * PLG + fpl) * A_PS + tap_off[i] + (r * QW + px) * 32 + foff);
+          for (int cg = 0; cg < NCIG; ++cg) bf[i][cg] = *(const float*)(abase[i] + cg * PLG * A_PS + (r * QW + ks * 2) * 32);
+        }
+      };
+      // the shared column's fragments for the group of four K steps starting at it4 (a group never straddles a strip row)
+      auto load_frags4 = [&](int it4, float (&af)[NCOG], float (&bf)[KH][NCIG]) {
+        const int r = it4 / NK, ks = it4 - r * NK;
 #pragma unroll
-          for (int i = 0; i < WT; ++i) {
-            if (i + 1 == WT && !last_tap_real) continue;
-            if (dead(i, r)) continue;
+        for (int cg = 0; cg < NCOG; ++cg) af[cg] = *(const float*)(dbase4 + cg * PLG * DY_PS + (r * SW + ks * 2) * 32);
+#pragma unroll
+        for (int i = 0; i < KH; ++i) {
+          if (dead(KH + i, r)) continue;
+#pragma unroll
+          for (int cg = 0; cg < NCIG; ++cg) bf[i][cg] = *(const float*)(abase[COL4 ? KH + i : 0] + cg * PLG * A_PS + (r * QW + ks * 2) * 32);
+        }
+      };
+      float af[2][NCOG], bf[2][WM][NCIG], af4[NCOG], bf4[KH][NCIG];
+      (void)af4; (void)bf4;
+      load_frags(0, af[0], bf[0]);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (COL4 && it % 4 == 0) load_frags4(it, af4, bf4);
+        if (it + 1 < NIT) load_frags(it + 1, af[(it + 1) & 1], bf[(it + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          if (dead(i, KSPLIT ? 0 : it / NK)) continue;
+#pragma unroll
+          for (int a = 0; a < NCOG; ++a)
+#pragma unroll
+            for (int c = 0; c < NCIG; ++c)
+              acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[it & 1][a], bf[it & 1][i][c], acc[i][a][c], 0, 0, 0);
+        }
+        if (COL4 && it % 4 == 3) {
+#pragma unroll
+          for (int i = 0; i < KH; ++i) {
+            if (dead(KH + i, it / NK)) continue;
 #pragma unroll
             for (int a = 0; a < NCOG; ++a)
 #pragma unroll
               for (int c = 0; c < NCIG; ++c)
-                acc[i][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[i][c], acc[i][a][c], 0, 0, 0);
+                acc[COL4 ? KH + i : 0][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af4[a], bf4[i][c], acc[COL4 ? KH + i : 0][a][c], 0, 0, 0);
           }
         }
       }
@@ -413,13 +459,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
+  if constexpr (COL4) {
+    // the shared column: accumulator KH + j of every wave is a partial sum of tap (kernel row j, last column) over that wave's
+    // K steps.  All partials go through LDS; wave j < KH adds the four of row j in the fixed order wave 0, 1, 2, 3 and stores
+    // the tap below (bitwise reproducible).
+    constexpr int PER = NCOG * NCIG * 16 * 64;               // floats of one accumulator set of one wave
+    static_assert(4 * KH * PER * 4 <= NBUF * BUF_BYTES, "cross-wave sums fit the staging buffers");
+    float* red = (float*)smem_all;
+    __syncthreads();                                         // every wave is done with the staged strips, every DMA has landed
+#pragma unroll
+    for (int j = 0; j < KH; ++j)
+#pragma unroll
+      for (int a = 0; a < NCOG; ++a)
+#pragma unroll
+        for (int c = 0; c < NCIG; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((wave * KH + j) * PER) + ((a * NCIG + c) * 16 + r) * 64 + lane] = acc[KH + j][a][c][r];
+    __syncthreads();
+    if (wave < KH) {
+#pragma unroll
+      for (int a = 0; a < NCOG; ++a)
+#pragma unroll
+        for (int c = 0; c < NCIG; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) t += red[((wv * KH + wave) * PER) + ((a * NCIG + c) * 16 + r) * 64 + lane];
+            acc[KH][a][c][r] = t;                             // accumulator KH now holds tap (kernel row `wave`, last column), complete
+          }
+    }
+  }
   // ---- write this block's partial tile(s)
   const int slab_idx = KSPLIT ? split * 4 + wave : split;
   float* slab = p.slab + (long)slab_idx * TAPS * p.co_pad * p.ci_pad;
 #pragma unroll
-  for (int i = 0; i < WT; ++i) {
-    const int tap = tap_of(i);
-    if (i + 1 < WT || last_tap_real) {
+  for (int i = 0; i < (COL4 ? KH + 1 : WT); ++i) {
+    // COL4: after the cross-wave sum accumulator KH is the last column's tap of kernel row `wave` (waves 0..KH-1)
+    const int tap = COL4 && i == KH ? min(wave, KH - 1) * KW + KW - 1 : tap_of(i);
+    if (COL4 ? (i < KH || wave < KH) : (i + 1 < WT || last_tap_real)) {
 #pragma unroll
       for (int a = 0; a < NCOG; ++a)
 #pragma unroll
