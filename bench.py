@@ -165,13 +165,19 @@ def cpu_baseline(rows: int, seconds_budget: float = 24.0):
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU legs
 # ---------------------------------------------------------------------------------------------------------------------
-KERNEL_SOURCES = ("conv_igemm.h", "conv_igemm8.h", "common.h", "api.hip", "conv8_inst_f32.hip", "conv_inst_bf16_k35.hip")   # what the dominant kernels are built from
+# what the kernels behind a bench tag are compiled from (profiles/r03_traffic.json records the hash of these files)
+TRAFFIC_SOURCES = {
+    "conv_igemm": ["conv_igemm.h", "common.h", "api.hip", "conv_inst_bf16_k35.hip", "conv_inst_f32_k35.hip"],
+    "conv_igemm8": ["conv_igemm8.h", "conv_igemm.h", "common.h", "api.hip", "conv8_inst_bf16.hip", "conv8_inst_f32.hip"],
+    "conv_igemm8c": ["conv_igemm8.h", "conv_igemm.h", "common.h", "api.hip", "conv8_inst_bf16.hip", "conv8_inst_f32.hip"],
+    "conv_wgrad": ["conv_wgrad.h", "common.h", "wgrad_api.hip", "wgrad_inst_bf16_k35.hip", "wgrad_inst_f32_k35.hip"],
+}
 
 
-def kernel_source_digest() -> str:
+def kernel_source_digest(names) -> str:
     import hashlib
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
+    for name in names:
         with open(os.path.join(ROOT, "dnanet_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -190,12 +196,12 @@ def hbm_traffic(tag, avg_launch_us):
             rec = json.load(f)
     except (OSError, ValueError):
         return None, None
-    rec = rec.get(tag) if "kernel" not in rec else (rec if rec.get("kernel") == tag else None)     # r03: one record per kernel tag
+    rec = rec.get(tag)                                  # one record per kernel tag
     if not rec:
         return None, None
     rel = os.path.relpath(TRAFFIC_PROFILE, ROOT)
     try:
-        if rec.get("kernel_source_sha256") != kernel_source_digest():
+        if rec.get("kernel_source_sha256") != kernel_source_digest(rec.get("sources", [])):
             return None, f"{rel} (not reported: the kernel's sources changed since the profile)"
     except OSError:
         return None, None
