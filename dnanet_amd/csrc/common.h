@@ -54,6 +54,7 @@ struct DnTune {
   int wgrad_noskip;     // DN_TUNE_WGRAD_NOSKIP: 1 = multiply the zero halo rows too, 2 = interleaved tap map
   bool wgrad_no_cot32;  // DN_TUNE_WGRAD_NO_COT32: 64-wide output-channel tile also for layers with <= 32 output channels
   bool wgrad_no_xcd;    // DN_TUNE_WGRAD_NO_XCD: weight-gradient blocks in plain (tile-fast) order, splits not tied to XCDs
+  long wgrad_minpx;     // DN_TUNE_WGRAD_MINPX: fewest pixels a split-K block of the 3x5 weight gradient may get (0 = default)
   bool no_convt_gemm;   // DN_TUNE_NO_CONVT_GEMM: transposed-convolution weight gradient on conv_wgrad.h's 1x1 kernel (the round-2 path)
 };
 inline const DnTune& dn_tune() {
@@ -73,6 +74,7 @@ inline const DnTune& dn_tune() {
     v.wgrad_no_cot32 = flag("DN_TUNE_WGRAD_NO_COT32");
     v.wgrad_no_xcd = flag("DN_TUNE_WGRAD_NO_XCD");
     v.no_convt_gemm = flag("DN_TUNE_NO_CONVT_GEMM");
+    if ((e = getenv("DN_TUNE_WGRAD_MINPX"))) v.wgrad_minpx = atol(e);
     return v;
   }();
   return t;

@@ -531,14 +531,19 @@ int conv_wgrad_launch(WgradParams p, long slab_bytes, int* nslab_out, hipStream_
   const long per_slab = (long)TAPS * p.co_pad * p.ci_pad * 4 * (KSPLIT ? 4 : 1);
   const long target = dn_tune().wgrad_blocks > 0 ? dn_tune().wgrad_blocks : 512;   // two resident workgroups per CU
   long nsplit = std::max<long>(1, (target + tiles - 1) / tiles);
-  // >= 2048 pixels per block: every slab costs a round trip through HBM
-  nsplit = std::min<long>(nsplit, std::max<long>(1, (long)p.nstrips * HT * SW / 2048));
+  // >= 2048 pixels per block: every slab costs a round trip through HBM.  Layers with few tiles get their blocks from
+  // the split alone, and at train.py's batch of 16 that floor left CUs without work (64 -> 64 channels at 2048 columns:
+  // 320 blocks); their slabs are small, so they may split further (measured at 16 profiles: fp32 234 -> 164 us on that
+  // layer, 143 -> 122 us on 32 -> 32; bf16 49 -> 41 us on 64 -> 128).  At 256 profiles neither floor binds.
+  const long small_px = sizeof(T) == 4 ? (tiles <= 8 ? 640 : 2048) : (tiles >= 2 && tiles <= 16 ? 1024 : 2048);
+  const long min_px = dn_tune().wgrad_minpx > 0 ? dn_tune().wgrad_minpx : small_px;
+  nsplit = std::min<long>(nsplit, std::max<long>(1, (long)p.nstrips * HT * SW / min_px));
   nsplit = std::min<long>(nsplit, slab_bytes / per_slab);
   // splits tied to XCDs need a multiple of 8 of them (else some XCDs would idle): round up when the workspace allows
   bool xcd = !dn_tune().wgrad_no_xcd;
   if (xcd && nsplit % 8) {
     const long up = (nsplit + 7) / 8 * 8;
-    if (up <= slab_bytes / per_slab && up <= std::max<long>(1, (long)p.nstrips * HT * SW / 1024)) nsplit = up; else xcd = false;
+    if (up <= slab_bytes / per_slab && up <= std::max<long>(1, (long)p.nstrips * HT * SW / (min_px / 2))) nsplit = up; else xcd = false;
   }
   if (nsplit >= p.nth) nsplit -= nsplit % p.nth;   // blocks of one height in the image (halo-row skipping)
   if (nsplit % 8) xcd = false;

@@ -669,6 +669,10 @@ class HipUNet(ParameterTree):
         S = self._saved
         if S is not None and S["n"] * S["h"] * S["w"] > self.two_stream_max_pixels:
             return None
+        # fp32 (round 3, N = 256): the fp32 matrix pipe is issue bound, not power bound, and a second stream's kernels only take
+        # issue slots from it -- 363.6 ms on one stream against 368.1 on two (5 dyes: 294.0 / 302.7); at 16 profiles equal
+        if S is not None and self.dtype == F32 and S["n"] * S["h"] * S["w"] > 2_000_000:
+            return None
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         return self._wgrad_stream

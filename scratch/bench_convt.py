@@ -3,7 +3,8 @@ import torch
 from dnanet_amd import hip
 dev = torch.device('cuda:0')
 n = 256; h = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-dtype = hip.BF16
+dtype = hip.F32 if len(sys.argv) > 2 and sys.argv[2] == 'fp32' else hip.BF16
+esz = 4 if dtype == hip.F32 else 2
 for cin, cout, win in [(512, 256, 256), (256, 128, 512), (128, 64, 1024), (64, 32, 2048)]:
     x = hip.PlaneBuffer(n, hip.planes(cin, dtype), h, win, dtype, dev); x.data.normal_()
     y = hip.PlaneBuffer(n, 2 * hip.planes(cout, dtype), h, 2 * win, dtype, dev)
@@ -20,5 +21,5 @@ for cin, cout, win in [(512, 256, 256), (256, 128, 512), (128, 64, 1024), (64, 3
     for _ in range(5): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    byts = n * h * win * (cin + 2 * cout) * 2
+    byts = n * h * win * (cin + 2 * cout) * esz
     print(f'convT {cin:4d}->{cout:4d} Win={win:5d}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s  {2.0*n*h*win*cin*cout*2/ms/1e9:7.1f} TF/s')

@@ -3,7 +3,7 @@ import torch
 from dnanet_amd import hip
 dev = torch.device('cuda:0')
 ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
-n, h = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 5
+n, h = int(sys.argv[3]) if len(sys.argv) > 3 else 256, int(sys.argv[1]) if len(sys.argv) > 1 else 5
 shapes = [(32, 32, 4096), (32, 64, 2048), (64, 64, 2048), (64, 128, 1024), (128, 128, 1024), (128, 256, 512), (256, 256, 512), (256, 512, 256), (512, 512, 256), (512, 256, 512), (64, 32, 4096)]
 dtype = hip.F32 if len(sys.argv) > 2 and sys.argv[2] == 'fp32' else hip.BF16
 peak = 2500.0 if dtype == hip.BF16 else 157.3

@@ -1,7 +1,7 @@
 """Per-layer table of the shipped net at batch 256: forward (eval, folded BN), training forward (+ statistics epilogue), data
 gradient and weight gradient of every 3x5 convolution, the transposed convolutions and the first convolution -- time,
 TFLOP/s, fraction of the dense bf16 MFMA peak and algorithmic GB/s (one read of the input, one write of the output).
-    python scratch/layer_table.py [rows=6] [dtype=bf16] > gpurun_out/layer_table.csv      (on the MI355X box)"""
+    python scratch/layer_table.py [rows=6] [dtype=bf16] [batch=256] > gpurun_out/layer_table.csv      (on the MI355X box)"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
 import torch
@@ -11,7 +11,7 @@ h = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dname = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 dtype = hip.BF16 if dname == 'bf16' else hip.F32
 peak = 2500.0 if dtype == hip.BF16 else 157.3
-n, eb = 256, (2 if dtype == hip.BF16 else 4)
+n, eb = (int(sys.argv[3]) if len(sys.argv) > 3 else 256), (2 if dtype == hip.BF16 else 4)
 ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 stat = torch.empty(64 << 20, dtype=torch.float32, device=dev)
 
