@@ -237,8 +237,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   // (KH-1): those products are left out at compile time for accumulators 0..2 (12 of the 15 taps) -- 11 % of the MFMAs
   // of a 5-row image.  Chosen once per block (the variants live outside the strip loop, inside it they cost 150
   // spilled registers): the strips of a block all sit at the same height of the image (see stage_begin).
-  auto strips = [&](auto top_c, auto bot_c) {
-  constexpr bool TOP = decltype(top_c)::value, BOT = decltype(bot_c)::value;
+  // LAST: this wave's last accumulator is a real tap (3x5, 4/4/4/3 map: waves 0..2).  A compile-time variant as well, so
+  // that the wave without one neither reads those fragments nor carries a branch per K step in its MFMA stream.
+  auto strips = [&](auto top_c, auto bot_c, auto last_c) {
+  constexpr bool TOP = decltype(top_c)::value, BOT = decltype(bot_c)::value, LAST = decltype(last_c)::value;
   auto dead = [&](int i, int r) -> bool {       // (accumulator, strip row) sees only a zero row of A
     if (KSPLIT || (!COL4 && i >= KH)) return false;        // 4/4/4/3 map: accumulator 3's kernel row depends on the wave
     const int krow = i % KH;                               // COL4: accumulators KH.. are the last column's rows
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         const int ks = s / HT, r = s - ks * HT;
 #pragma unroll
         for (int cg = 0; cg < NCOG; ++cg) af[s & 1][cg] = rd(dbase0 + cg * PLG * DY_PS + (r * SW + ks * 16) * 32);
-        bx[s & 1] = rd(abase0 + tap_off[KH] + (r * QW + ks * 16) * 32);
+        if constexpr (LAST) bx[s & 1] = rd(abase0 + tap_off[KH] + (r * QW + ks * 16) * 32);
 #pragma unroll
         for (int rho = 0; rho < HT + KH - 1; ++rho) {
           if (rho > r + KH - 1 || (r > 0 && rho < r + KH - 1)) continue;        // new rows of the window only
@@ -310,9 +312,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
             acc[i][a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s & 1][a]),
                                                                    __builtin_bit_cast(bf16x8_t, g[ks][r + i]), acc[i][a][0], 0, 0, 0);
         }
-        // the extra tap (column KW-1 of kernel row `wave`); the wave without one reads its fragments (no branch in the
-        // read stream) but skips the MFMAs, which are what the power budget pays for
-        if (last_tap_real) {
+        // the extra tap (column KW-1 of kernel row `wave`); the wave without one runs the variant compiled without it
+        if constexpr (LAST) {
 #pragma unroll
           for (int a = 0; a < NCOG; ++a)
             acc[KH][a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[s & 1][a]),
@@ -451,11 +452,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const bool fixed_height = p.skip_halo == 1 && p.nsplit % p.nth == 0;
     const int th = split % p.nth;
     const bool top = fixed_height && th == 0, bot = fixed_height && th == p.nth - 1;   // block-uniform
-    if constexpr (KH == 1) strips(no{}, no{});
-    else if (top && bot) strips(yes{}, yes{});
-    else if (top) strips(yes{}, no{});
-    else if (bot) strips(no{}, yes{});
-    else strips(no{}, no{});
+    constexpr bool WINDOW = sizeof(T) == 2 && !KSPLIT;      // the only path with a per-wave LAST variant
+    auto run = [&](auto t, auto b) {
+      if (!WINDOW || last_tap_real) strips(t, b, yes{}); else strips(t, b, no{});
+    };
+    if constexpr (KH == 1) strips(no{}, no{}, yes{});
+    else if (top && bot) run(yes{}, yes{});
+    else if (top) run(yes{}, no{});
+    else if (bot) run(no{}, yes{});
+    else run(no{}, no{});
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the wave
