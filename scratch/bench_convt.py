@@ -21,5 +21,12 @@ for cin, cout, win in [(512, 256, 256), (256, 128, 512), (128, 64, 1024), (64, 3
     for _ in range(5): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
+    pkd = torch.empty(hip.lib.dn_packed_weight_bytes(cout, cin, 1, 2, hip.PACK_CONVT_DGRAD, dtype), dtype=torch.uint8, device=dev)
+    hip.check(hip.lib.dn_pack_weight(hip.ptr(w), None, hip.ptr(pkd), cout, cin, 1, 2, hip.PACK_CONVT_DGRAD, dtype, hip.stream_ptr()))
+    def run2():
+        hip.check(hip.lib.dn_conv_transpose_1x2_dgrad(y.ref(cout, 0), hip.ptr(pkd), x.ref(cin), n, h, win, dtype, hip.stream_ptr()))
+    run2(); torch.cuda.synchronize(); e0.record()
+    for _ in range(5): run2()
+    e1.record(); torch.cuda.synchronize(); ms2 = e0.elapsed_time(e1) / 5
     byts = n * h * win * (cin + 2 * cout) * esz
-    print(f'convT {cin:4d}->{cout:4d} Win={win:5d}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s  {2.0*n*h*win*cin*cout*2/ms/1e9:7.1f} TF/s')
+    print(f'convT {cin:4d}->{cout:4d} Win={win:5d}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s  {2.0*n*h*win*cin*cout*2/ms/1e9:7.1f} TF/s | dgrad {ms2*1e3:8.1f} us', flush=True)
