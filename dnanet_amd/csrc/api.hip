@@ -55,6 +55,12 @@ static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t
   if (dtype != DN_BF16 && dtype != DN_F32) return dn_set_error(DN_ERR_ARG, "bad dtype %d", dtype);
   const ConvVariant v = choose_variant(p, kh, kw, dtype);
   const int ht = v.ht, cot = v.cot;
+  if (p.bn_y) {                      // data gradient + BatchNorm backward sums of the unit it feeds
+    if (!(kh == 3 && kw == 5)) return dn_set_error(DN_ERR_UNSUPPORTED, "BatchNorm-sums epilogue: kernel size (%d,%d) is not built (have (3,5))", kh, kw);
+    if (p.bias || p.relu || p.y_wmul != 1 || !p.stats) return dn_set_error(DN_ERR_ARG, "BatchNorm-sums epilogue: a plain data gradient only");
+    if (v.wave8) return dtype == DN_BF16 ? conv_igemm8_run_bf16_bnred(p, ht, s) : conv_igemm8_run_f32_bnred(p, ht, s);
+    return dtype == DN_BF16 ? conv_igemm_run_bf16_k35_bnred(p, ht, cot, s) : conv_igemm_run_f32_k35_bnred(p, ht, cot, s);
+  }
   if (p.y_lo_off) {                  // hi + lo split output (bf16x3 inference mode)
     if (dtype != DN_BF16) return dn_set_error(DN_ERR_ARG, "split output needs bf16 storage");
     if (v.wave8) return conv_igemm8_run_bf16_split(p, ht, s);
@@ -100,9 +106,10 @@ int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, in
   return DN_OK;
 }
 
+struct BnSums { dn_tensor y; const float *scale, *shift, *mean, *invstd; };   // the unit a data gradient feeds (CONV_EPI_BNRED)
 static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
                        int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream,
-                       const dn_tensor* pooled = nullptr);
+                       const dn_tensor* pooled = nullptr, const BnSums* bn = nullptr);
 
 // The fused head needs the whole channel dimension of a pixel in one block: the tile the dispatcher picks for this
 // shape must be as wide as the padded channel count.
@@ -158,6 +165,19 @@ int dn_conv2d_stats(dn_tensor x, const void* packed_w, const float* bias, dn_ten
   DN_CHECK_ARG(partial && ntiles, "dn_conv2d_stats: null pointer");
   DN_CHECK_ARG((kh == 3 && kw == 5) || (kh == 1 && kw == 3), "dn_conv2d_stats: kernel size (%d,%d) has no statistics epilogue", kh, kw);
   return conv2d_impl(x, packed_w, bias, y, N, H, W, kh, kw, 0, dtype, partial, partial_floats, ntiles, stream);
+}
+
+int dn_conv2d_dgrad_bn_sums(dn_tensor dy, const void* packed_wd, dn_tensor dx, dn_tensor bn_y, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, int N, int H, int W, int kh, int kw,
+                            int dtype, float* partial, long partial_floats, int* ntiles, void* stream) {
+  DN_CHECK_ARG(partial && ntiles && bn_y.base && scale && shift && mean && invstd, "dn_conv2d_dgrad_bn_sums: null pointer");
+  DN_CHECK_ARG(kh == 3 && kw == 5, "dn_conv2d_dgrad_bn_sums: kernel size (%d,%d) has no BatchNorm-sums epilogue", kh, kw);
+  DN_CHECK_ARG(bn_y.channels == dx.channels, "dn_conv2d_dgrad_bn_sums: bn_y has %d channels, dx %d", bn_y.channels, dx.channels);
+  const int bp = dn_planes(bn_y.channels, dtype);
+  DN_CHECK_ARG(bn_y.plane0 >= 0 && bn_y.plane0 + bp <= bn_y.planes_total, "dn_conv2d_dgrad_bn_sums: bn_y planes [%d,%d) outside buffer of %d",
+               bn_y.plane0, bn_y.plane0 + bp, bn_y.planes_total);
+  const BnSums bn{bn_y, scale, shift, mean, invstd};
+  return conv2d_impl(dy, packed_wd, nullptr, dx, N, H, W, kh, kw, 0, dtype, partial, partial_floats, ntiles, stream, nullptr, &bn);
 }
 
 int dn_conv2d(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
@@ -277,7 +297,8 @@ int dn_conv_transpose_1x2_x3(dn_tensor_x3 x, const void* packed_w, const float* 
 }  // extern "C"
 
 static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_tensor y, int N, int H, int W, int kh, int kw,
-                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream, const dn_tensor* pooled) {
+                       int relu, int dtype, float* stats, long stats_capacity, int* ntiles, void* stream, const dn_tensor* pooled,
+                       const BnSums* bn) {
   DN_CHECK_ARG(x.base && packed_w && y.base, "dn_conv2d: null pointer");
   DN_CHECK_ARG(N > 0 && H > 0 && W > 0 && x.channels > 0 && y.channels > 0, "dn_conv2d: bad shape N=%d H=%d W=%d", N, H, W);
   DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv2d: bad dtype %d", dtype);
@@ -292,6 +313,10 @@ static int conv2d_impl(dn_tensor x, const void* packed_w, const float* bias, dn_
   p.y = y.base; p.y_planes_total = y.planes_total; p.y_plane0 = y.plane0; p.y_nplanes = yp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
   p.N = N; p.H = H; p.W = W; p.nchunk = xp; p.cout_pad = dn_channel_pad(y.channels); p.relu = relu;
   if (pooled) { p.pool = pooled->base; p.pool_planes_total = pooled->planes_total; p.pool_plane0 = pooled->plane0; }
+  if (bn) {
+    p.bn_y = bn->y.base; p.bn_planes_total = bn->y.planes_total; p.bn_plane0 = bn->y.plane0;
+    p.bn_scale = bn->scale; p.bn_shift = bn->shift; p.bn_mean = bn->mean; p.bn_invstd = bn->invstd;
+  }
   if (stats) {
     p.stats = stats;
     const ConvVariant v = choose_variant(p, kh, kw, dtype);

@@ -35,7 +35,11 @@ struct ConvParams {
   int cout_pad;             // multiple of COT
   int relu;
   int ntw, nth;             // column / row tiles per image
-  float* stats;             // BatchNorm partial sums [pixel tile][cout_pad][2] (CONV_EPI_STATS instantiations), else unused
+  float* stats;             // BatchNorm partial sums [pixel tile][cout_pad][2] (CONV_EPI_STATS / CONV_EPI_BNRED), else unused
+  // CONV_EPI_BNRED (a data gradient whose output is dL/d(activation) of a BatchNorm + ReLU unit): that unit's saved
+  // convolution output (same channels and pixel grid as y) and its per-channel vectors [cout_pad]
+  const void* bn_y; int bn_planes_total, bn_plane0;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
   void* pool; int pool_planes_total, pool_plane0;   // MaxPool2d((1,2)) of y, W/2 columns (CONV_EPI_POOL), else unused
   const float* head_w; const float* head_b;         // 1x1 head over the tile's channels (CONV_EPI_HEAD): y is not stored,
   float* head_logits; float* head_probs;            // logits / sigmoid go to [N][H][W] fp32 (either may be null)
@@ -68,6 +72,8 @@ constexpr int CONV_EPI_POOL = 2;    // + MaxPool2d((1,2)) of y into a second buf
 constexpr int CONV_EPI_HEAD = 3;    // instead of storing y: the 1x1 output convolution + sigmoid over it (last block, eval mode)
 constexpr int CONV_EPI_SPLIT = 4;   // bf16 only: y = hi + lo, two bf16 tensors p.y_lo_off planes apart (~16 mantissa bits kept)
 constexpr int CONV_EPI_POOL_SPLIT = 5;   // SPLIT + POOL (the pooled tensor split too when p.pool_lo_off > 0)
+constexpr int CONV_EPI_BNRED = 6;   // + the two sums of BatchNorm's backward over the stored y (= g of the unit that produced this
+                                    //   convolution's input): sum dz and sum dz * xhat, dz = g * (bn_y * scale + shift > 0)
 
 // Head form of the epilogue (unet_architecture.py:94-97 + trainable_unet.py:409 fused into the last DoubleConv): the
 // block holds every channel of its pixels (cout_pad == COT), a lane 16 of them, so logit = sum_c w_c * act_c + b is a
@@ -132,6 +138,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
                                                     int cot, int lane) {
   constexpr bool STATS = EPI == CONV_EPI_STATS, POOL = EPI == CONV_EPI_POOL || EPI == CONV_EPI_POOL_SPLIT;
   constexpr bool SPLIT = EPI == CONV_EPI_SPLIT || EPI == CONV_EPI_POOL_SPLIT;
+  constexpr bool BNRED = EPI == CONV_EPI_BNRED;
   static_assert(!SPLIT || sizeof(T) == 2, "hi + lo split exists for bf16 storage only");
   constexpr int NPART = SPLIT ? 2 : 1;          // part 0 stores bf16(v), part 1 bf16(v - bf16(v)) y_lo_off planes further
   constexpr int NCG = COT / 32, EPR = RecTraits<T>::EPR, GPL = 32 / EPR;
@@ -147,15 +154,51 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
   const bool col_ok = wbase + l31 < p.W;
   // ReLU as ONE v_max per value against a per-launch floor (0 or -inf) instead of a max and a select on p.relu
   const float floor_v = p.relu ? 0.f : -__builtin_inff();
+  // BNRED (a data gradient: no bias, no ReLU -- the dispatcher checks): the consumer unit's per-channel vectors
+  // [scale | shift | mean | invstd][COT] go to LDS once per block, in the pooled-output scratch this form does not use
+  float* bn_k = nullptr;
+  (void)bn_k;
+  if constexpr (BNRED) {
+    bn_k = (float*)(pool_scratch - (threadIdx.x >> 6) * ((COT / EPR) * 512));
+    if (threadIdx.x < COT) {
+      const int ch = cot * COT + threadIdx.x;
+      bn_k[threadIdx.x] = p.bn_scale[ch]; bn_k[COT + threadIdx.x] = p.bn_shift[ch];
+      bn_k[2 * COT + threadIdx.x] = p.bn_mean[ch]; bn_k[3 * COT + threadIdx.x] = p.bn_invstd[ch];
+    }
+  }
+  // ... and the unit's saved convolution output at this lane's pixels, four channels (one lane group g of a 32-channel
+  // accumulator tile) per piece and row: the first BN_PF groups are requested here, before the stores, so that they have
+  // arrived when the sums are formed; group k + BN_PF is requested when group k is done
+  using bn_piece_t = std::conditional_t<sizeof(T) == 2, uint2, uint4>;
+  constexpr int BN_NG = NCG * 4, BN_REGS = HT * (int)(sizeof(bn_piece_t) / 4);
+  constexpr int BN_BUDGET = 36;   // registers for pieces in flight: what the 3-row x 64-channel tile has left at three workgroups per CU
+  constexpr int BN_PF = !BNRED ? 1 : (BN_BUDGET / BN_REGS >= BN_NG ? BN_NG : (BN_BUDGET / BN_REGS >= 2 ? BN_BUDGET / BN_REGS : 2));
+  bn_piece_t bn_yv[BN_PF][HT];
+  (void)bn_yv;
+  auto bn_fetch = [&](int gi) {
+    const int ch = cot * COT + (gi >> 2) * 32 + 8 * (gi & 3) + 4 * half;
+    const int plane = ch / EPR;                                  // wave-uniform: 4 * half stays inside a record
+#pragma unroll
+    for (int hh = 0; hh < HT; ++hh) {
+      bn_yv[gi % BN_PF][hh] = bn_piece_t{};
+      if (plane < p.y_nplanes && h0 + hh < p.H && col_ok)
+        bn_yv[gi % BN_PF][hh] = *(const bn_piece_t*)((const unsigned char*)p.bn_y +
+            ((((long)n * p.bn_planes_total + p.bn_plane0 + plane) * p.H + h0 + hh) * p.W + wbase + l31) * 32 + (ch % EPR) * sizeof(T));
+    }
+  };
+  if constexpr (BNRED) {
+#pragma unroll
+    for (int gi = 0; gi < BN_PF; ++gi) bn_fetch(gi);
+  }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     float ssum[STATS_INLOOP ? 16 : 1] = {}, ssq[STATS_INLOOP ? 16 : 1] = {};
     (void)ssum; (void)ssq;
-    float bias_r[CPP][16];
+    float bias_r[CPP][BNRED ? 1 : 16];
 #pragma unroll
     for (int c = 0; c < CPP; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
+      for (int r = 0; r < (BNRED ? 1 : 16); ++r)
         bias_r[c][r] = p.bias ? p.bias[cot * COT + (ps * CPP + c) * 32 + 8 * (r >> 2) + 4 * half + (r & 3)] : 0.f;
 #pragma unroll
     for (int hh = 0; hh < HT; ++hh) {
@@ -171,7 +214,8 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              v[i] = fmaxf(acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i], floor_v);
+              if constexpr (BNRED) v[i] = acc[hh][c][4 * g + i];
+              else v[i] = fmaxf(acc[hh][ps * CPP + c][4 * g + i] + bias_r[c][4 * g + i], floor_v);
             }
             unsigned char* dst = scratch + (cl / EPR) * 1024 + l31 * 32 + (cl % EPR) * sizeof(T);
             if constexpr (sizeof(T) == 4) {
@@ -268,7 +312,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
        }
       }
     }
-    if constexpr (STATS) {
+    if constexpr (STATS || BNRED) {
       // Sum over the 32 pixel lanes of each half-wave, four channels (a lane's accumulator group g) at a time: the eight
       // values [s0..s3, q0..q3] go through a butterfly that halves the number of live values per step -- lane bit 0
       // decides who keeps the sums and who the squares, bit 1 who keeps channels 0,1 and who 2,3 (DPP quad permutes) --
@@ -301,7 +345,60 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvParams& p, f32x16_
           }
         }
       };
-      if constexpr (STATS_INLOOP) {
+      if constexpr (BNRED) {
+        // BatchNorm backward's two sums for the unit whose activation gradient this tile just stored (train_ops.hip,
+        // bn_bwd_reduce_kernel), on the values as stored.  A further walk over the accumulators, four channels (one 8- or
+        // 16-byte piece of the unit's saved convolution output per row) at a time.  A lane sums dz and dz * y over its
+        // rows and turns the second into sum dz * xhat = (sum dz*y - mean * sum dz) * invstd before the lanes are added
+        // up: two per-channel vectors less in the inner loop, and at most 6 terms under the subtraction.
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        __syncthreads();                                               // bn_k is filled (all waves are past their stores)
+#pragma unroll
+        for (int gi = 0; gi < BN_NG; ++gi) {
+          const int c = gi >> 2, g = gi & 3, cl = c * 32 + 8 * g + 4 * half;
+          float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+          if ((cot * COT + cl) / EPR < p.y_nplanes) {   // wave-uniform
+            const float4 k0 = *(const float4*)(bn_k + cl), k1 = *(const float4*)(bn_k + COT + cl);
+            const float4 k2 = *(const float4*)(bn_k + 2 * COT + cl), k3 = *(const float4*)(bn_k + 3 * COT + cl);
+            const float sc[4] = {k0.x, k0.y, k0.z, k0.w}, sh[4] = {k1.x, k1.y, k1.z, k1.w};
+            const float mu[4] = {k2.x, k2.y, k2.z, k2.w}, is[4] = {k3.x, k3.y, k3.z, k3.w};
+            const bn_piece_t (&yv)[HT] = bn_yv[gi % BN_PF];
+#pragma unroll
+            for (int hh = 0; hh < HT; ++hh) {
+              if (h0 + hh < p.H) {                      // block-uniform
+                float fy[4];
+                if constexpr (sizeof(T) == 2) {
+                  fy[0] = __uint_as_float(yv[hh].x << 16); fy[1] = __uint_as_float(yv[hh].x & 0xffff0000u);
+                  fy[2] = __uint_as_float(yv[hh].y << 16); fy[3] = __uint_as_float(yv[hh].y & 0xffff0000u);
+                } else {
+                  fy[0] = __uint_as_float(yv[hh].x); fy[1] = __uint_as_float(yv[hh].y);
+                  fy[2] = __uint_as_float(yv[hh].z); fy[3] = __uint_as_float(yv[hh].w);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                  f32x2_t v = {acc[hh][c][4 * g + 2 * k], acc[hh][c][4 * g + 2 * k + 1]};
+                  if constexpr (sizeof(T) == 2) {       // the gradient as stored
+                    const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                    v = (f32x2_t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+                  }
+#pragma unroll
+                  for (int i = 0; i < 2; ++i) {
+                    const int j = 2 * k + i;
+                    const float dz = (col_ok && fmaf(fy[j], sc[j], sh[j]) > 0.f) ? v[i] : 0.f;   // the forward's own pre-ReLU value
+                    s4[j] += dz;
+                    q4[j] = fmaf(dz, fy[j], q4[j]);
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q4[j] = (q4[j] - mu[j] * s4[j]) * is[j];
+          }
+          if (gi + BN_PF < BN_NG) bn_fetch(gi + BN_PF);
+          publish4(c, g, s4, q4);
+        }
+      } else if constexpr (STATS_INLOOP) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float s4[4] = {ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]};
@@ -560,8 +657,9 @@ __global__ __launch_bounds__(256, MINB) void conv_igemm_kernel(const ConvParams 
   if constexpr (EPI == CONV_EPI_HEAD) conv_epilogue_head<T, HT, COT>(p, acc, n, h0, w0 + 32 * wave, lane);
   else conv_epilogue_store<T, HT, COT, EPI, KH == 1 && KW == 1>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
                                             pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
-  if constexpr (STATS) {
-    // BatchNorm statistics of this tile: partial[pixel tile][channel][sum, sum of squares] (bn_finalize_kernel's layout)
+  if constexpr (STATS || EPI == CONV_EPI_BNRED) {
+    // BatchNorm statistics of this tile: partial[pixel tile][channel][sum, sum of squares] (bn_finalize_kernel's layout);
+    // BNRED: [sum dz, sum dz * xhat] (bn_bwd_finalize_kernel's)
     __syncthreads();
     if (tid < COT * 2) {
       float t = 0.f;

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8_kernel(const ConvParams p)
   }
 #endif
   // BatchNorm statistics of this 256-column tile: sum the 8 waves' (sum, sum of squares), fixed order
-  if constexpr (STATS) {
+  if constexpr (STATS || EPI == CONV_EPI_BNRED) {
     __syncthreads();
     if (tid < COT * 2) {
       float t = 0.f;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm8c_kernel(const ConvParams p
   conv_epilogue_store<T, HT, COT, EPI>(p, acc, smem_all + wave * (NPL * 1024), stat_lds + wave * COT * 2,
                                        pool_lds + wave * (NPL * 512), n, h0, w0 + 32 * wave, cot, lane);
   // BatchNorm statistics of this 256-column tile: sum the 8 waves' (sum, sum of squares), fixed order
-  if constexpr (STATS) {
+  if constexpr (STATS || EPI == CONV_EPI_BNRED) {
     __syncthreads();
     if (tid < COT * 2) {
       float t = 0.f;

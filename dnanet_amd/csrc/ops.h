@@ -11,6 +11,8 @@ int conv_igemm_run_bf16_k35_split(const ConvParams& p, int ht, int cot, hipStrea
 int conv_igemm_run_bf16_k13_split(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_bf16_k11_split(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k35(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_bf16_k35_bnred(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_f32_k35_bnred(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k13(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k11(const ConvParams& p, int ht, int cot, hipStream_t s);
 
@@ -18,6 +20,8 @@ int conv_igemm_run_f32_k11(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm8_run_bf16(const ConvParams& p, int ht, hipStream_t s);
 int conv_igemm8_run_bf16_split(const ConvParams& p, int ht, hipStream_t s);
 int conv_igemm8_run_f32(const ConvParams& p, int ht, hipStream_t s);
+int conv_igemm8_run_bf16_bnred(const ConvParams& p, int ht, hipStream_t s);
+int conv_igemm8_run_f32_bnred(const ConvParams& p, int ht, hipStream_t s);
 
 #include "conv_wgrad.h"
 int conv_wgrad_run_bf16_k35(const WgradParams& p, long slab_bytes, int* nslab, hipStream_t s);

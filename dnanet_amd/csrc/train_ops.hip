@@ -139,23 +139,27 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const unsigned ch
 // Sum of the [nblk][cpad] (sum, sum of squares) partial pairs of channel c over a 256-thread block, fixed order, fp64.
 // With the statistics fused into the convolution there is one partial per conv tile (thousands): every thread keeps four
 // pairs in flight.  The result is valid in thread 0.
+constexpr int SUM_THREADS = 1024;   // threads of the kernels that add up per-tile partials: one block per channel
 __device__ __forceinline__ void block_sum_pairs(const float* partial, int nblk, int cpad, int c, double& s_out, double& ss_out) {
   const float2* p = (const float2*)partial + c;
   double s = 0.0, ss = 0.0;
   int i = threadIdx.x;
-  for (; i + 768 < nblk; i += 1024) {
-    const float2 a = p[(long)i * cpad], b = p[(long)(i + 256) * cpad], d = p[(long)(i + 512) * cpad], e = p[(long)(i + 768) * cpad];
+  for (; i + 3 * SUM_THREADS < nblk; i += 4 * SUM_THREADS) {
+    const float2 a = p[(long)i * cpad], b = p[(long)(i + SUM_THREADS) * cpad], d = p[(long)(i + 2 * SUM_THREADS) * cpad],
+                 e = p[(long)(i + 3 * SUM_THREADS) * cpad];
     s += ((double)a.x + (double)b.x) + ((double)d.x + (double)e.x);
     ss += ((double)a.y + (double)b.y) + ((double)d.y + (double)e.y);
   }
-  for (; i < nblk; i += 256) { const float2 a = p[(long)i * cpad]; s += a.x; ss += a.y; }
+  for (; i < nblk; i += SUM_THREADS) { const float2 a = p[(long)i * cpad]; s += a.x; ss += a.y; }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); ss += __shfl_xor(ss, m); }
-  __shared__ double red[4][2];
+  __shared__ double red[SUM_THREADS / 64][2];
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = ss; }
   __syncthreads();
-  s_out = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-  ss_out = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  s = 0.0; ss = 0.0;
+#pragma unroll
+  for (int w = 0; w < SUM_THREADS / 64; ++w) { s += red[w][0]; ss += red[w][1]; }   // fixed order
+  s_out = s; ss_out = ss;
 }
 
 // mean, invstd, running statistics, fused scale / shift of one channel from its totals over `count` values
@@ -182,7 +186,7 @@ __device__ __forceinline__ void bn_finalize_channel(int c, double s, double ss, 
 __global__ void bn_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                    float* mean_out, float* invstd_out, float* scale, float* shift) {
-  const int c = blockIdx.x;       // one 256-thread block per channel
+  const int c = blockIdx.x;       // one SUM_THREADS block per channel
   if (c >= C) { if (threadIdx.x == 0) { scale[c] = 0.f; shift[c] = 0.f; mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
   double s, ss;
   block_sum_pairs(partial, nblk, cpad, c, s, ss);
@@ -317,12 +321,13 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const unsign
   block_reduce_store<2, PN>(acc, partial, cpad, plane, EPR);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count, const float* gamma,
-                                       const float* invstd, float* dgamma, float* dbeta, float* coef /*[3][cpad]*/) {
-  const int c = blockIdx.x;       // one wave per channel
+__global__ __launch_bounds__(SUM_THREADS) void bn_bwd_finalize_kernel(const float* partial, int nblk, int cpad, int C, double count,
+                                                                      const float* gamma, const float* invstd, float* dgamma,
+                                                                      float* dbeta, float* coef /*[3][cpad]*/) {
+  const int c = blockIdx.x;       // one block per channel: the partials are per reduction block, or per convolution tile
   if (c >= C) { if (threadIdx.x == 0) { coef[c] = 0.f; coef[cpad + c] = 0.f; coef[2 * cpad + c] = 0.f; } return; }
-  const double s1 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2);
-  const double s2 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2 + 1);
+  double s1, s2;
+  block_sum_pairs(partial, nblk, cpad, c, s1, s2);
   if (threadIdx.x != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
@@ -333,13 +338,10 @@ __global__ void bn_bwd_finalize_kernel(const float* partial, int nblk, int cpad,
 
 // synchronised form: local totals -> (all-reduce by the caller) -> coefficients from the global totals.  dgamma / dbeta stay
 // LOCAL sums: the data-parallel gradient all-reduce adds them up like every other parameter gradient.
-__global__ void bn_bwd_pair_totals_kernel(const float* partial, int nblk, int cpad, int C, double* totals) {
-  const int c = blockIdx.x;       // one wave per channel
+__global__ __launch_bounds__(SUM_THREADS) void bn_bwd_pair_totals_kernel(const float* partial, int nblk, int cpad, int C, double* totals) {
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    s1 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2);
-    s2 = wave_sum_partials(partial, nblk, (long)cpad * 2, (long)c * 2 + 1);
-  }
+  if (c < C) block_sum_pairs(partial, nblk, cpad, c, s1, s2);
   if (threadIdx.x == 0) { totals[2 * c] = s1; totals[2 * c + 1] = s2; }
 }
 
@@ -720,7 +722,7 @@ static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, 
     "dn_bn_train_forward");
   }
   DN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(256), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cpad), dim3(SUM_THREADS), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   }
   DN_LAUNCH_CHECK();
@@ -750,7 +752,7 @@ static int bn_train_forward_impl(dn_tensor y, dn_tensor a, int N, int H, int W, 
 int dn_bn_partial_totals(const float* partial, int ntiles, int C, double* totals, void* stream) {
   DN_CHECK_ARG(partial && totals && ntiles > 0 && C > 0, "dn_bn_partial_totals: bad argument");
   const int cpad = dn_channel_pad(C);
-  hipLaunchKernelGGL(bn_pair_totals_kernel, dim3(cpad), dim3(256), 0, (hipStream_t)stream, partial, ntiles, cpad, C, totals);
+  hipLaunchKernelGGL(bn_pair_totals_kernel, dim3(cpad), dim3(SUM_THREADS), 0, (hipStream_t)stream, partial, ntiles, cpad, C, totals);
   DN_LAUNCH_CHECK();
   return DN_OK;
 }
@@ -766,13 +768,29 @@ int dn_bn_train_apply_totals(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, 
 static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
                                   const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                                   float* partial, int dtype, void* stream, int phase, double* local_totals,
-                                  const double* global_totals, double count);
+                                  const double* global_totals, double count, int given_nblk = 0);
 
 int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
                          const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                          float* partial, int dtype, void* stream) {
   return bn_train_backward_impl(g, y, scale, shift, N, H, W, gamma, mean, invstd, dgamma, dbeta, coef, partial, dtype, stream, 0,
                                 nullptr, nullptr, 0);
+}
+
+int dn_bn_train_backward_sums(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                              const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                              const float* sums, int ntiles, int dtype, void* stream) {
+  DN_CHECK_ARG(sums && ntiles > 0, "dn_bn_train_backward_sums: no sums");
+  return bn_train_backward_impl(g, y, scale, shift, N, H, W, gamma, mean, invstd, dgamma, dbeta, coef, (float*)sums, dtype, stream, 0,
+                                nullptr, nullptr, 0, ntiles);
+}
+
+int dn_bn_backward_sums_totals(const float* sums, int ntiles, int channels, double* totals, void* stream) {
+  DN_CHECK_ARG(sums && totals && ntiles > 0 && channels > 0, "dn_bn_backward_sums_totals: bad argument");
+  const int cpad = dn_channel_pad(channels);
+  hipLaunchKernelGGL(bn_bwd_pair_totals_kernel, dim3(cpad), dim3(SUM_THREADS), 0, (hipStream_t)stream, sums, ntiles, cpad, channels, totals);
+  DN_LAUNCH_CHECK();
+  return DN_OK;
 }
 
 int dn_bn_train_backward_totals(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
@@ -796,7 +814,8 @@ int dn_bn_train_backward_apply_totals(dn_tensor g, dn_tensor y, const float* sca
 static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
                                   const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                                   float* partial, int dtype, void* stream, int phase, double* local_totals,
-                                  const double* global_totals, double count) {
+                                  const double* global_totals, double count, int given_nblk) {
+  // given_nblk > 0: `partial` already holds [given_nblk][cpad][2] sums (dn_conv2d_dgrad_bn_sums), the reduction pass is skipped
   DN_CHECK_ARG(g.base && y.base && scale && shift && mean && invstd, "dn_bn_train_backward: null pointer");
   DN_CHECK_ARG(phase == 2 || partial, "dn_bn_train_backward: no partial workspace");
   DN_CHECK_ARG(phase == 1 || (gamma && dgamma && dbeta && coef), "dn_bn_train_backward: null pointer");
@@ -804,9 +823,9 @@ static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, 
   const int C = y.channels, cpad = dn_channel_pad(C), nplanes = dn_planes(C, dtype);
   const long HW = (long)H * W;
   DN_CHECK_ARG(HW * 2 < (1L << 31) && N < 65536 && nplanes < 65536, "dn_bn_train_backward: plane too large for the launch grid");
-  const int nblk = red_blocks((long)N * HW);
+  const int nblk = given_nblk > 0 ? given_nblk : red_blocks((long)N * HW);
   hipStream_t s = (hipStream_t)stream;
-  if (phase != 2) {
+  if (phase != 2 && given_nblk <= 0) {
 #define ARGS_R (const unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)y.base, y.planes_total, y.plane0, \
                scale, shift, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), mean, invstd, partial, cpad
     DN_DISPATCH_T(dtype,
@@ -817,7 +836,7 @@ static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, 
     DN_LAUNCH_CHECK();
   }
   if (phase == 1) {
-    hipLaunchKernelGGL(bn_bwd_pair_totals_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, local_totals);
+    hipLaunchKernelGGL(bn_bwd_pair_totals_kernel, dim3(cpad), dim3(SUM_THREADS), 0, s, partial, nblk, cpad, C, local_totals);
     DN_LAUNCH_CHECK();
     return DN_OK;
   }
@@ -825,7 +844,7 @@ static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, 
     hipLaunchKernelGGL(bn_bwd_finalize_totals_kernel, dim3((cpad + 63) / 64), dim3(64), 0, s, local_totals, global_totals, cpad, C,
                        count, gamma, invstd, dgamma, dbeta, coef);
   else
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cpad), dim3(64), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cpad), dim3(SUM_THREADS), 0, s, partial, nblk, cpad, C, (double)N * HW, gamma,
                        invstd, dgamma, dbeta, coef);
   DN_LAUNCH_CHECK();
   const int npieces = (int)(HW * 2);

@@ -93,6 +93,10 @@ _SIGS = {
     "dn_conv2d_head_supported": (c_int, [c_int] * 8),
     "dn_conv2d_head": (c_int, [DnTensor, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "dn_conv_first_stats": (c_int, [_P, _P, _P, DnTensor, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, POINTER(c_int), _P]),
+    "dn_conv2d_dgrad_bn_sums": (c_int, [DnTensor, _P, DnTensor, DnTensor, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                        c_long, POINTER(c_int), _P]),
+    "dn_bn_train_backward_sums": (c_int, [DnTensor, DnTensor, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "dn_bn_backward_sums_totals": (c_int, [_P, c_int, c_int, _P, _P]),
     "dn_conv2d_stats": (c_int, [DnTensor, _P, _P, DnTensor, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, POINTER(c_int), _P]),
     "dn_bn_train_apply": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
                                   c_int, c_int, _P]),

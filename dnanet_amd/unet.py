@@ -80,6 +80,8 @@ class HipUNet(ParameterTree):
         # backward chain reads dW), MFMA-bound, and overlap the HBM-bound BatchNorm / pooling passes of the following
         # units on the main stream.  DN_TUNE_NO_WGRAD_STREAM=1 keeps everything on one stream (A/B switch).
         self.overlap_wgrad = self.flat_params.is_cuda and not os.environ.get("DN_TUNE_NO_WGRAD_STREAM")
+        # BatchNorm backward's sums in the epilogue of the data gradient that produces the unit's activation gradient
+        self.fuse_bn_sums = not os.environ.get("DN_TUNE_NO_BN_SUMS")
         self._wgrad_stream = None
         self.two_stream_max_pixels = 20_000_000       # N*H*W above which backward stays on one stream (see _side)
         # Device memory of the passes: one StepArena per (kind of pass, batch shape), allocated by the first pass at that
@@ -700,17 +702,23 @@ class HipUNet(ParameterTree):
         with torch.cuda.stream(side):
             segment_hook(name)
 
-    def _unit_backward(self, u: ConvUnit, g, want_dgrad: bool):
-        """g: dL/d(output activation) in a buffer (overwritten with dL/dy). Returns dL/d(input) ref."""
+    def _unit_backward(self, u: ConvUnit, g, want_dgrad: bool, feeds: Optional[ConvUnit] = None, sums=None):
+        """g: dL/d(output activation) in a buffer (overwritten with dL/dy). Returns dL/d(input) ref.
+        ``feeds``: the unit whose activation is this unit's input -- the data gradient then forms that unit's BatchNorm
+        backward sums in its epilogue and the buffer returned carries them as ``.bn_sums`` = (sums, ntiles), which the
+        caller hands to that unit's call as ``sums`` (its reduction pass over g and y is skipped)."""
         ws, cache, sv, A = self._workspace(), self._train_cache, self._saved[u.conv], self._saved["arena"]
         n, h, w = sv["n"], sv["h"], sv["w"]
         kh, kw = self.kernel_size
         if self.sync_bn is not None:
             all_reduce, world = self.sync_bn
             local = A.take((2 * hip.channel_pad(u.cout),), torch.float64)
-            hip.check(hip.lib.dn_bn_train_backward_totals(g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
-                                                          hip.ptr(sv["mean"]), hip.ptr(sv["invstd"]), hip.ptr(ws["partial"]),
-                                                          hip.ptr(local), self.dtype, hip.stream_ptr()))
+            if sums is not None:
+                hip.check(hip.lib.dn_bn_backward_sums_totals(hip.ptr(sums[0]), sums[1], u.cout, hip.ptr(local), hip.stream_ptr()))
+            else:
+                hip.check(hip.lib.dn_bn_train_backward_totals(g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
+                                                              hip.ptr(sv["mean"]), hip.ptr(sv["invstd"]), hip.ptr(ws["partial"]),
+                                                              hip.ptr(local), self.dtype, hip.stream_ptr()))
             total = A.take(tuple(local.shape), torch.float64)
             total.copy_(local)
             all_reduce(total)
@@ -719,6 +727,12 @@ class HipUNet(ParameterTree):
                 hip.ptr(sv["mean"]), hip.ptr(sv["invstd"]), hip.ptr(local), hip.ptr(total), float(n * h * w * world),
                 hip.ptr(self.grad(u.bn + ".weight")), hip.ptr(self.grad(u.bn + ".bias")), hip.ptr(ws["coef"]), self.dtype,
                 hip.stream_ptr()))
+        elif sums is not None:
+            hip.check(hip.lib.dn_bn_train_backward_sums(
+                g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
+                hip.ptr(self.tensor(u.bn + ".weight")), hip.ptr(sv["mean"]),
+                hip.ptr(sv["invstd"]), hip.ptr(self.grad(u.bn + ".weight")), hip.ptr(self.grad(u.bn + ".bias")),
+                hip.ptr(ws["coef"]), hip.ptr(sums[0]), sums[1], self.dtype, hip.stream_ptr()))
         else:
             hip.check(hip.lib.dn_bn_train_backward(
                 g, sv["y"].ref(u.cout), hip.ptr(sv["scale"]), hip.ptr(sv["shift"]), n, h, w,
@@ -741,6 +755,21 @@ class HipUNet(ParameterTree):
             return None
         cin_stored = sv["src"].channels
         gin = PlaneBuffer(n, self._pp(cin_stored), h, w, self.dtype, self.device, arena=A)
+        gin.bn_sums = None
+        if feeds is not None and self.fuse_bn_sums and (kh, kw) == (3, 5) and feeds.cout == cin_stored:
+            fv = self._saved[feeds.conv]
+            cp = hip.channel_pad(feeds.cout)
+            need = n * ((h + 2) // 3) * ((w + 127) // 128) * cp * 2       # tiles are at least 3 rows x 128 columns
+            if ws.get("bnsums") is None or ws["bnsums"].numel() < need:
+                ws["bnsums"] = torch.empty(need, dtype=torch.float32, device=self.device)
+            ntiles = ctypes.c_int(0)
+            self._timed(lambda: self.conv_kernel_tag(u.cout, cin_stored, n, h, w) + "+bnsums:dgrad", flops,
+                        lambda: hip.check(hip.lib.dn_conv2d_dgrad_bn_sums(
+                            g, hip.ptr(cache[u.conv]["wd"]), gin.ref(cin_stored), fv["y"].ref(feeds.cout), hip.ptr(fv["scale"]),
+                            hip.ptr(fv["shift"]), hip.ptr(fv["mean"]), hip.ptr(fv["invstd"]), n, h, w, kh, kw, self.dtype,
+                            hip.ptr(ws["bnsums"]), ws["bnsums"].numel(), ctypes.byref(ntiles), hip.stream_ptr())))
+            gin.bn_sums = (ws["bnsums"], ntiles.value)
+            return gin
         self._timed(lambda: self.conv_kernel_tag(u.cout, cin_stored, n, h, w) + ":dgrad", flops, lambda: hip.check(hip.lib.dn_conv2d(
             g, hip.ptr(cache[u.conv]["wd"]), None, gin.ref(cin_stored), n, h, w, kh, kw, 0, self.dtype, hip.stream_ptr())))
         return gin
@@ -777,9 +806,9 @@ class HipUNet(ParameterTree):
         for i in reversed(range(depth)):
             l = depth - 1 - i
             pre = f"decoders.{i}.conv.double_conv"
-            g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True)
+            g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True, feeds=units[pre + ".0"])
             done(cur)
-            gcat[l] = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), True)
+            gcat[l] = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), True, sums=g1.bn_sums)
             done(g1)
             d_up = gcat[l].ref(c[l], 0)
             upn = f"decoders.{i}.up"
@@ -796,9 +825,9 @@ class HipUNet(ParameterTree):
             if segment_hook:
                 self._segment_done(segment_hook, f"decoders.{i}")
         pre = "bottleneck.double_conv"
-        g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[depth]), True)
+        g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[depth]), True, feeds=units[pre + ".0"])
         done(cur)
-        gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[depth]), True)
+        gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[depth]), True, sums=g1.bn_sums)
         done(g1)
         if segment_hook:
             self._segment_done(segment_hook, "bottleneck")
@@ -810,9 +839,9 @@ class HipUNet(ParameterTree):
                                                       wl[l + 1], dt, hip.stream_ptr()))
             done(gpool)
             done(gcat[l])
-            g1 = self._unit_backward(units[pre + ".3"], g2.ref(c[l]), True)
+            g1 = self._unit_backward(units[pre + ".3"], g2.ref(c[l]), True, feeds=units[pre + ".0"])
             done(g2)
-            gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), l > 0)
+            gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), l > 0, sums=g1.bn_sums)
             done(g1)
             if segment_hook:
                 self._segment_done(segment_hook, f"encoders.{l}")

@@ -208,6 +208,20 @@ int dn_bn_train_apply_pool(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, in
 int dn_bn_train_backward(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
                          const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                          float* partial, int dtype, void* stream);
+/* The data gradient of a DoubleConv's second convolution (autograd of nn.Conv2d, unet_architecture.py:14-20, under
+ * trainable_unet.py:342) together with the reduction pass of dn_bn_train_backward for the unit that produced the
+ * convolution's input: dx = dL/d(activation of that unit) as dn_conv2d(dy, packed_wd, relu = 0) writes it, and per pixel
+ * tile and channel the two sums { sum dz, sum dz * xhat } over the values of dx as stored, dz = dx * (bn_y * scale +
+ * shift > 0), xhat = (bn_y - mean) * invstd -- sums[tile][dn_channel_pad(C)][2], *ntiles tiles.  bn_y: that unit's saved
+ * convolution output (the channels and pixel grid of dx), scale / shift / mean / invstd: the vectors its forward saved
+ * ([dn_channel_pad(C)]).  dx is read back one time less.  Kernel size (3,5). */
+int dn_conv2d_dgrad_bn_sums(dn_tensor dy, const void* packed_wd, dn_tensor dx, dn_tensor bn_y, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, int N, int H, int W, int kh, int kw,
+                            int dtype, float* sums, long sums_floats, int* ntiles, void* stream);
+/* dn_bn_train_backward without its reduction pass: sums / ntiles come from dn_conv2d_dgrad_bn_sums. */
+int dn_bn_train_backward_sums(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
+                              const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                              const float* sums, int ntiles, int dtype, void* stream);
 /* ---- synchronised BatchNorm (optional, data parallel; NO COUNTERPART IN THE REFERENCE, which is single-device: this is what
  * makes "R ranks x N/R profiles" compute the batch statistics -- hence the results -- of one device at batch N, the only
  * oracle a data-parallel run has).  Forward: dn_conv2d_stats / dn_conv_first_stats -> dn_bn_partial_totals ->
@@ -224,6 +238,8 @@ int dn_bn_train_apply_totals(dn_tensor y, dn_tensor a, dn_tensor pooled, int N, 
 /* First half of dn_bn_train_backward: totals[c][2] = { sum dz, sum dz * xhat } of this rank (g is not modified). */
 int dn_bn_train_backward_totals(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,
                                 const float* mean, const float* invstd, float* partial, double* totals, int dtype, void* stream);
+/* dn_bn_train_backward_totals without its reduction pass (sums / ntiles from dn_conv2d_dgrad_bn_sums). */
+int dn_bn_backward_sums_totals(const float* sums, int ntiles, int C, double* totals, void* stream);
 /* Second half: g -> dL/dy with the batch means taken from global_totals / count; dgamma / dbeta are this rank's sums
  * (local_totals), which the data-parallel gradient all-reduce adds up like every other parameter gradient. */
 int dn_bn_train_backward_apply_totals(dn_tensor g, dn_tensor y, const float* scale, const float* shift, int N, int H, int W,

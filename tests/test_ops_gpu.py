@@ -277,6 +277,97 @@ def test_conv2d_dgrad(gpu_device, case, dtype):
     assert torch.equal(dxb.to_nchw(cin).cpu(), _q(ref, dtype))
 
 
+BN_SUMS_CASES = [
+    # n, cin (channels of dx = of the BatchNorm unit), cout (channels of dy), h, w -> the tile the dispatcher picks
+    (2, 32, 32, 5, 64), (3, 24, 16, 6, 200), (2, 72, 64, 5, 300), (1, 128, 32, 3, 128), (2, 64, 64, 6, 130), (2, 32, 64, 6, 256),
+    (130, 32, 32, 5, 512), (2, 8, 8, 7, 96),
+    (8, 512, 64, 5, 2048), (8, 512, 64, 6, 2048),                  # 8-wave kernels (fp32: both; bf16: the 5-row one)
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", BN_SUMS_CASES)
+def test_conv2d_dgrad_bn_sums(gpu_device, case, dtype):
+    """dn_conv2d_dgrad_bn_sums: dx bitwise the plain data gradient's, and per-tile sums whose totals are BatchNorm
+    backward's reduction over the stored dx (against fp64 on the CPU and against dn_bn_train_backward_totals); then
+    dn_bn_train_backward_sums = dn_bn_train_backward on the same tensors."""
+    import ctypes
+    hip = _hip()
+    dev = gpu_device
+    n, cin, cout, h, w = case
+    kh, kw = 3, 5
+    g = torch.Generator().manual_seed(23 + dtype)
+    dy = torch.randint(-1, 2, (n, cout, h, w), generator=g).float()
+    wt = torch.randint(-1, 2, (cout, cin, kh, kw), generator=g).float()
+    if cin == 512:
+        tag = _variant(hip, cout, cin, n, h, w, kh, kw, dtype)
+        assert tag.startswith("conv_igemm8") == (h == 5 or dtype == 0), tag
+    dyb = hip.PlaneBuffer.from_nchw(dy.to(dev), dtype)
+    packed = _pack(hip, wt, None, hip.PACK_DGRAD, dtype, dev)
+    plain = hip.PlaneBuffer(n, hip.planes(cin, dtype), h, w, dtype, dev, zero=True)
+    hip.check(hip.lib.dn_conv2d(dyb.ref(cout), hip.ptr(packed), None, plain.ref(cin), n, h, w, kh, kw, 0, dtype, hip.stream_ptr()))
+    # the unit the gradient feeds: values for which y*scale + shift and (y - mean)*invstd are exact in fp32 and never 0
+    y = torch.randint(-4, 5, (n, cin, h, w), generator=g).float()
+    yb = hip.PlaneBuffer.from_nchw(y.to(dev), dtype)
+    cp = hip.channel_pad(cin)
+    pick = lambda vals: torch.tensor(vals)[torch.randint(0, len(vals), (cin,), generator=g)]
+    scale, shift = pick([-2.0, -1.0, -0.5, 0.5, 1.0, 2.0]), torch.randint(-3, 4, (cin,), generator=g).float() + 0.25
+    mean, invstd = torch.randint(-4, 5, (cin,), generator=g).float() * 0.5, pick([0.5, 1.0, 2.0])
+    vec = torch.full((4 * cp,), float("nan"), device=dev)           # the padding entries are never read into a result
+    vs = [vec[i * cp:(i + 1) * cp] for i in range(4)]
+    for dst, src in zip(vs, (scale, shift, mean, invstd)):
+        dst[:cin] = src.to(dev)
+    dxb = hip.PlaneBuffer(n, hip.planes(cin, dtype), h, w, dtype, dev, zero=True)
+    cap = n * ((h + 2) // 3) * ((w + 127) // 128) * cp * 2
+    sums = torch.full((cap,), float("nan"), device=dev)
+    ntiles = ctypes.c_int(0)
+    args = (dyb.ref(cout), hip.ptr(packed), dxb.ref(cin), yb.ref(cin), hip.ptr(vs[0]), hip.ptr(vs[1]), hip.ptr(vs[2]), hip.ptr(vs[3]),
+            n, h, w, kh, kw, dtype, hip.ptr(sums))
+    hip.check(hip.lib.dn_conv2d_dgrad_bn_sums(*args, cap, ctypes.byref(ntiles), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dxb.data, plain.data)
+    dx = dxb.to_nchw(cin).cpu().double()
+    t = ntiles.value
+    assert 0 < t and t * cp * 2 <= cap
+    got = sums[:t * cp * 2].view(t, cp, 2).double().sum(0).cpu()
+    bc = lambda v: v.double().view(1, -1, 1, 1)
+    dz = dx * ((y.double() * bc(scale) + bc(shift)) > 0)
+    want = torch.stack([dz.sum((0, 2, 3)), (dz * (y.double() - bc(mean)) * bc(invstd)).sum((0, 2, 3))], 1)
+    assert float(want.abs().max()) > 0
+    assert torch.allclose(got[:cin], want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    # the two-pass path on the same tensors
+    part = torch.empty(hip.partial_floats(cin), device=dev)
+    tot_a, tot_b = torch.zeros(2 * cp, dtype=torch.float64, device=dev), torch.zeros(2 * cp, dtype=torch.float64, device=dev)
+    hip.check(hip.lib.dn_bn_train_backward_totals(dxb.ref(cin), yb.ref(cin), hip.ptr(vs[0]), hip.ptr(vs[1]), n, h, w, hip.ptr(vs[2]),
+                                                  hip.ptr(vs[3]), hip.ptr(part), hip.ptr(tot_a), dtype, hip.stream_ptr()))
+    hip.check(hip.lib.dn_bn_backward_sums_totals(hip.ptr(sums), t, cin, hip.ptr(tot_b), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    a, b = tot_a.view(cp, 2)[:cin].cpu(), tot_b.view(cp, 2)[:cin].cpu()
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * float(a.abs().max()))
+    assert float(tot_b.view(cp, 2)[cin:].abs().max()) == 0 if cp > cin else True
+    gamma = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    outs = []
+    for fused in (False, True):
+        gb = hip.PlaneBuffer(n, hip.planes(cin, dtype), h, w, dtype, dev, zero=True)
+        gb.data.copy_(dxb.data)
+        dgam, dbet, coef = torch.empty(cin, device=dev), torch.empty(cin, device=dev), torch.empty(3 * cp, device=dev)
+        common = (gb.ref(cin), yb.ref(cin), hip.ptr(vs[0]), hip.ptr(vs[1]), n, h, w, hip.ptr(gamma), hip.ptr(vs[2]), hip.ptr(vs[3]),
+                  hip.ptr(dgam), hip.ptr(dbet), hip.ptr(coef))
+        if fused:
+            hip.check(hip.lib.dn_bn_train_backward_sums(*common, hip.ptr(sums), t, dtype, hip.stream_ptr()))
+        else:
+            hip.check(hip.lib.dn_bn_train_backward(*common, hip.ptr(part), dtype, hip.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((gb.to_nchw(cin).cpu(), dgam.cpu(), dbet.cpu()))
+    tol = 1e-5 if dtype == 0 else 1e-2
+    for u, v in zip(*outs):
+        assert torch.allclose(u, v, rtol=tol, atol=tol * float(v.abs().max()))
+    # too small a buffer, a bias-carrying or non-3x5 call are refused, not overrun
+    assert hip.lib.dn_conv2d_dgrad_bn_sums(*args, 16, ctypes.byref(ntiles), hip.stream_ptr()) != 0
+    bad = list(args); bad[11], bad[12] = 1, 3
+    assert hip.lib.dn_conv2d_dgrad_bn_sums(*bad, cap, ctypes.byref(ntiles), hip.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 64, 32, 5, 64), (1, 32, 16, 6, 48), (2, 128, 64, 5, 128), (1, 16, 8, 5, 32),
                                   (2, 48, 64, 6, 256), (2, 128, 40, 6, 256)])   # 128-row tiles, two K planes per barrier (odd / even plane counts)

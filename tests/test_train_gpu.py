@@ -134,3 +134,31 @@ def test_small_net_large_pixel_count_vs_oracle(gpu_device, cfg):
     rc = hip.lib.dn_conv_first_wgrad(hip.ptr(x.to(gpu_device)), dy.ref(filters), hip.ptr(dw), hip.ptr(small), small.numel(), n, 5, 4096,
                                      3, 5, hip.F32, hip.stream_ptr())
     assert rc == 1 and b"partial buffer" in hip.lib.dn_last_error()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["g_d3_k35_f8_h5_w128", "g_d2_k35_f8_h6_w96"])
+def test_bn_sums_in_the_data_gradient_epilogue_equal_the_reduction_pass(gpu_device, name, dtype):
+    """The first unit of every DoubleConv gets BatchNorm backward's two sums from the epilogue of the data gradient that
+    writes its activation gradient (dn_conv2d_dgrad_bn_sums) instead of from a pass over g and y.  Same per-element
+    arithmetic, another order of summation: every gradient of a backward pass agrees with the two-pass path to rounding."""
+    from dnanet_amd.unet import HipUNet
+    g = load_golden(name)
+    x, t = torch.from_numpy(g["x"]).to(gpu_device), torch.from_numpy(g["t"]).to(gpu_device)
+    grads, calls = [], []
+    for fused in (True, False):
+        m = HipUNet(int(g["depth"]), tuple(int(v) for v in g["kernel"]), int(g["filters"]), gpu_device, dtype=dtype)
+        m.load_state_dict(g["sd0"])
+        m.train()
+        m.fuse_bn_sums = fused
+        m.profile = []                      # records the launches by tag
+        m.flat_grads.zero_()
+        m.dice_forward(m(x), t)
+        m.backward()
+        torch.cuda.synchronize()
+        calls.append(sum("+bnsums:dgrad" in str(rec[0]) for rec in m.profile))
+        grads.append(m.flat_grads.clone())
+    assert calls == [2 * int(g["depth"]) + 1, 0], calls
+    a, b = grads
+    rel = float((a - b).norm() / b.norm())
+    assert rel < (1e-5 if dtype == "fp32" else 2e-3), rel
