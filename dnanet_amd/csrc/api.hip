@@ -190,7 +190,6 @@ int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2,
   DN_CHECK_ARG(x.base && packed_w && y.base, "dn_conv_transpose_1x2: null pointer");
   DN_CHECK_ARG(N > 0 && H > 0 && Win > 0, "dn_conv_transpose_1x2: bad shape");
   DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_transpose_1x2: bad dtype %d", dtype);
-  const int epr = dtype == DN_BF16 ? 16 : 8;
   const int xp = dn_planes(x.channels, dtype), yp = dn_planes(y.channels, dtype);
   DN_CHECK_ARG(x.plane0 + xp <= x.planes_total && y.plane0 + yp <= y.planes_total, "dn_conv_transpose_1x2: planes outside buffer");
   const int gsize = dn_channel_pad(y.channels);

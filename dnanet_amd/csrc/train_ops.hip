@@ -432,6 +432,68 @@ __global__ __launch_bounds__(256) void pool_bwd_add_kernel(const unsigned char* 
   }
 }
 
+// The same with BatchNorm backward's two sums for the unit whose activation x is (the second unit of an encoder block):
+// g is that unit's activation gradient, so sum dz and sum dz * xhat are formed here, on the values of g as stored, and
+// the unit's reduction pass over g and y is not needed (bn_bwd_reduce_kernel's arithmetic and partial layout; work split
+// as there: (image, segment) units of a plane dealt round-robin to the blocks, a thread's piece parity fixed).
+// An item = one pooled pixel x one 16-byte piece: two neighbouring full-resolution records.
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void pool_bwd_add_sums_kernel(
+    const unsigned char* x, int x_pt, int x_p0, const unsigned char* dpool, int dp_pt, int dp_p0, const unsigned char* dskip,
+    int ds_pt, int ds_p0, unsigned char* g, int g_pt, int g_p0, const unsigned char* y, int y_pt, int y_p0,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int N, int nitems /* 2 * H * Wout */, int seg_len, float* partial, int cpad) {
+  constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
+  const int plane = blockIdx.y, pc = threadIdx.x & 1;
+  const int c0 = plane * EPR + pc * PN;
+  float mu[PN], is[PN], sc[PN], sh[PN];
+#pragma unroll
+  for (int j = 0; j < PN; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+  float acc[2][PN] = {};
+  const int nseg = (nitems + seg_len - 1) / seg_len;
+  for (int u = blockIdx.x; u < N * nseg; u += gridDim.x) {
+    const int n = u / nseg, seg = u - n * nseg;
+    // 16-byte pieces of this image's plane: full resolution 2 * nitems of them, pooled nitems
+    const unsigned char* xb = x + ((long)n * x_pt + x_p0 + plane) * nitems * 32;
+    const unsigned char* yb = y + ((long)n * y_pt + y_p0 + plane) * nitems * 32;
+    const unsigned char* sb = dskip ? dskip + ((long)n * ds_pt + ds_p0 + plane) * nitems * 32 : nullptr;
+    unsigned char* gb = g + ((long)n * g_pt + g_p0 + plane) * nitems * 32;
+    const unsigned char* pb = dpool + ((long)n * dp_pt + dp_p0 + plane) * nitems * 16;
+    const int iend = min(nitems, (seg + 1) * seg_len);
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += RED_THREADS) {
+      const long full = (long)(i >> 1) * 64 + 16 * pc;      // byte offset of the even column's piece; the odd one is 32 further
+      float x0[PN], x1[PN], dp[PN], s0[PN] = {}, s1[PN] = {}, y0[PN], y1[PN];
+      const uint4 vx0 = *(const uint4*)(xb + full), vx1 = *(const uint4*)(xb + full + 32);
+      const uint4 vdp = *(const uint4*)(pb + (long)i * 16);
+      const uint4 vy0 = *(const uint4*)(yb + full), vy1 = *(const uint4*)(yb + full + 32);
+      if (sb) {
+        Piece<T>::unpack(*(const uint4*)(sb + full), s0);
+        Piece<T>::unpack(*(const uint4*)(sb + full + 32), s1);
+      }
+      Piece<T>::unpack(vx0, x0); Piece<T>::unpack(vx1, x1); Piece<T>::unpack(vdp, dp);
+      Piece<T>::unpack(vy0, y0); Piece<T>::unpack(vy1, y1);
+#pragma unroll
+      for (int j = 0; j < PN; ++j) {
+        const bool first = x0[j] >= x1[j];       // ties go to the first element (ATen max_pool2d backward)
+        s0[j] += first ? dp[j] : 0.f;
+        s1[j] += first ? 0.f : dp[j];
+      }
+      const uint4 g0 = Piece<T>::pack(s0), g1 = Piece<T>::pack(s1);
+      *(uint4*)(gb + full) = g0;
+      *(uint4*)(gb + full + 32) = g1;
+      Piece<T>::unpack(g0, s0); Piece<T>::unpack(g1, s1);          // the gradient as stored
+#pragma unroll
+      for (int j = 0; j < PN; ++j) {
+        const float dz0 = fmaf(y0[j], sc[j], sh[j]) > 0.f ? s0[j] : 0.f;
+        const float dz1 = fmaf(y1[j], sc[j], sh[j]) > 0.f ? s1[j] : 0.f;
+        acc[0][j] += dz0 + dz1;
+        acc[1][j] = fmaf(dz1, (y1[j] - mu[j]) * is[j], fmaf(dz0, (y0[j] - mu[j]) * is[j], acc[1][j]));
+      }
+    }
+  }
+  block_reduce_store<2, PN>(acc, partial, cpad, plane, EPR);
+}
+
 // ---- head backward ---------------------------------------------------------------------------------
 // g[n,c,h,w] = dlogit[n,h,w] * w[c]
 template <typename T>
@@ -451,6 +513,47 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
     for (int j = 0; j < PN; ++j) f[j] = d * w[pl * EPR + pc * PN + j];
     *(uint4*)(g + rec_off(g_pt, g_p0 + pl, n, hw, HW) + 16 * pc) = Piece<T>::pack(f);
   }
+}
+
+// The same with BatchNorm backward's two sums of the unit whose activation the head reads (the last DoubleConv's second
+// unit): g is its activation gradient.  Work split and partial layout as bn_bwd_reduce_kernel.
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void head_bwd_data_sums_kernel(
+    const float* __restrict__ dlogit, const float* __restrict__ w, unsigned char* g, int g_pt, int g_p0, const unsigned char* y,
+    int y_pt, int y_p0, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int N, int npieces /* 2 * H * W */, int seg_len, float* partial, int cpad) {
+  constexpr int PN = Piece<T>::N, EPR = RecTraits<T>::EPR;
+  const int plane = blockIdx.y, pc = threadIdx.x & 1;
+  const int c0 = plane * EPR + pc * PN;
+  float mu[PN], is[PN], sc[PN], sh[PN], wv[PN];
+#pragma unroll
+  for (int j = 0; j < PN; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; wv[j] = w[c0 + j]; }
+  float acc[2][PN] = {};
+  const int nseg = (npieces + seg_len - 1) / seg_len;
+  for (int u = blockIdx.x; u < N * nseg; u += gridDim.x) {
+    const int n = u / nseg, seg = u - n * nseg;
+    unsigned char* gb = g + ((long)n * g_pt + g_p0 + plane) * npieces * 16;
+    const unsigned char* yb = y + ((long)n * y_pt + y_p0 + plane) * npieces * 16;
+    const float* dl = dlogit + (long)n * (npieces >> 1);
+    const int iend = min(npieces, (seg + 1) * seg_len);
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += RED_THREADS) {
+      const float d = dl[i >> 1];
+      float f[PN], fy[PN];
+      Piece<T>::unpack(*(const uint4*)(yb + (long)i * 16), fy);
+#pragma unroll
+      for (int j = 0; j < PN; ++j) f[j] = d * wv[j];
+      const uint4 gv = Piece<T>::pack(f);
+      *(uint4*)(gb + (long)i * 16) = gv;
+      Piece<T>::unpack(gv, f);                                       // the gradient as stored
+#pragma unroll
+      for (int j = 0; j < PN; ++j) {
+        const float dz = fmaf(fy[j], sc[j], sh[j]) > 0.f ? f[j] : 0.f;
+        acc[0][j] += dz;
+        acc[1][j] = fmaf(dz, (fy[j] - mu[j]) * is[j], acc[1][j]);
+      }
+    }
+  }
+  block_reduce_store<2, PN>(acc, partial, cpad, plane, EPR);
 }
 
 // per-channel sum over pixels of x * (scale ? scale[pixel] : 1):  head weight gradient (scale = dlogit),
@@ -860,12 +963,45 @@ static int bn_train_backward_impl(dn_tensor g, dn_tensor y, const float* scale, 
   return DN_OK;
 }
 
-int dn_maxpool_1x2_backward(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, int N, int H, int Wout, int dtype,
-                            void* stream) {
+// the BatchNorm unit whose activation gradient a producer writes: saved convolution output and per-channel vectors
+struct BnUnit { dn_tensor y; const float *scale, *shift, *mean, *invstd; float* sums; long sums_floats; int* nblk; };
+
+static int bn_unit_check(const BnUnit& bn, int channels, int dtype, long pixels, const char* who) {
+  DN_CHECK_ARG(bn.y.base && bn.scale && bn.shift && bn.mean && bn.invstd && bn.sums && bn.nblk, "%s: null pointer", who);
+  DN_CHECK_ARG(bn.y.channels == channels, "%s: bn_y has %d channels, g %d", who, bn.y.channels, channels);
+  const int bp = dn_planes(channels, dtype);
+  DN_CHECK_ARG(bn.y.plane0 >= 0 && bn.y.plane0 + bp <= bn.y.planes_total, "%s: bn_y planes [%d,%d) outside buffer of %d", who,
+               bn.y.plane0, bn.y.plane0 + bp, bn.y.planes_total);
+  const long need = (long)red_blocks(pixels) * dn_channel_pad(channels) * 2;
+  DN_CHECK_ARG(need <= bn.sums_floats, "%s: sums buffer of %ld floats, need %ld", who, bn.sums_floats, need);
+  return DN_OK;
+}
+
+static int maxpool_backward_impl(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, int N, int H, int Wout, int dtype,
+                                 void* stream, const BnUnit* bn) {
   DN_CHECK_ARG(x.base && dpool.base && g.base, "dn_maxpool_1x2_backward: null pointer");
   DN_CHECK_ARG(x.channels == dpool.channels && x.channels == g.channels && (!dskip.base || dskip.channels == x.channels),
                "dn_maxpool_1x2_backward: channel mismatch");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_maxpool_1x2_backward: bad dtype %d", dtype);
   const int nplanes = dn_planes(x.channels, dtype);
+  if (bn) {
+    const long pix = (long)N * H * Wout * 2;
+    if (int rc = bn_unit_check(*bn, x.channels, dtype, pix, "dn_maxpool_1x2_backward_bn_sums")) return rc;
+    DN_CHECK_ARG((long)H * Wout * 4 < (1L << 31) && nplanes < 65536, "dn_maxpool_1x2_backward_bn_sums: plane too large for the launch grid");
+    const int nblk = red_blocks(pix), nitems = 2 * H * Wout, cpad = dn_channel_pad(x.channels);
+#define ARGS_S (const unsigned char*)x.base, x.planes_total, x.plane0, (const unsigned char*)dpool.base, dpool.planes_total, dpool.plane0, \
+               (const unsigned char*)dskip.base, dskip.planes_total, dskip.plane0, (unsigned char*)g.base, g.planes_total, g.plane0, \
+               (const unsigned char*)bn->y.base, bn->y.planes_total, bn->y.plane0, bn->scale, bn->shift, bn->mean, bn->invstd, N, \
+               nitems, red_seg(N, nplanes, nitems), bn->sums, cpad
+    DN_DISPATCH_T(dtype,
+      hipLaunchKernelGGL(pool_bwd_add_sums_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, (hipStream_t)stream, ARGS_S),
+      hipLaunchKernelGGL(pool_bwd_add_sums_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, (hipStream_t)stream, ARGS_S),
+      "dn_maxpool_1x2_backward_bn_sums");
+#undef ARGS_S
+    DN_LAUNCH_CHECK();
+    *bn->nblk = nblk;
+    return DN_OK;
+  }
   const long total = (long)N * nplanes * H * Wout * 2;
 #define ARGS (const unsigned char*)x.base, x.planes_total, x.plane0, (const unsigned char*)dpool.base, dpool.planes_total, dpool.plane0, \
              (const unsigned char*)dskip.base, dskip.planes_total, dskip.plane0, (unsigned char*)g.base, g.planes_total, g.plane0, \
@@ -879,8 +1015,35 @@ int dn_maxpool_1x2_backward(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_te
   return DN_OK;
 }
 
+int dn_maxpool_1x2_backward(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, int N, int H, int Wout, int dtype,
+                            void* stream) {
+  return maxpool_backward_impl(x, dpool, dskip, g, N, H, Wout, dtype, stream, nullptr);
+}
+
+int dn_maxpool_1x2_backward_bn_sums(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, dn_tensor bn_y, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, int N, int H, int Wout, int dtype,
+                                    float* sums, long sums_floats, int* nblk, void* stream) {
+  const BnUnit bn{bn_y, scale, shift, mean, invstd, sums, sums_floats, nblk};
+  return maxpool_backward_impl(x, dpool, dskip, g, N, H, Wout, dtype, stream, &bn);
+}
+
+static int head_backward_impl(const float* dlogits, dn_tensor x, const float* w, dn_tensor g, float* dw, float* db, float* partial,
+                              int N, int H, int W, int dtype, void* stream, const BnUnit* bn);
+
 int dn_head_1x1_backward(const float* dlogits, dn_tensor x, const float* w, dn_tensor g, float* dw, float* db, float* partial,
                          int N, int H, int W, int dtype, void* stream) {
+  return head_backward_impl(dlogits, x, w, g, dw, db, partial, N, H, W, dtype, stream, nullptr);
+}
+
+int dn_head_1x1_backward_bn_sums(const float* dlogits, dn_tensor x, const float* w, dn_tensor g, float* dw, float* db, float* partial,
+                                 dn_tensor bn_y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                 int N, int H, int W, int dtype, float* sums, long sums_floats, int* nblk, void* stream) {
+  const BnUnit bn{bn_y, scale, shift, mean, invstd, sums, sums_floats, nblk};
+  return head_backward_impl(dlogits, x, w, g, dw, db, partial, N, H, W, dtype, stream, &bn);
+}
+
+static int head_backward_impl(const float* dlogits, dn_tensor x, const float* w, dn_tensor g, float* dw, float* db, float* partial,
+                              int N, int H, int W, int dtype, void* stream, const BnUnit* bn) {
   DN_CHECK_ARG(dlogits && x.base && w && g.base && dw && db && partial, "dn_head_1x1_backward: null pointer");
   DN_CHECK_ARG(x.channels == g.channels, "dn_head_1x1_backward: channel mismatch");
   DN_CHECK_ARG(N > 0 && (long)H * W > 0 && (long)H * W * 2 < (1L << 31), "dn_head_1x1_backward: bad shape / plane too large");
@@ -888,12 +1051,25 @@ int dn_head_1x1_backward(const float* dlogits, dn_tensor x, const float* w, dn_t
   const long HW = (long)H * W;
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)N * nplanes * HW * 2;
-  DN_DISPATCH_T(dtype,
-    hipLaunchKernelGGL(head_bwd_data_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), 0, s, dlogits, w, (unsigned char*)g.base, g.planes_total, g.plane0, nplanes, (long)N, HW),
-    hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, dlogits, w, (unsigned char*)g.base, g.planes_total, g.plane0, nplanes, (long)N, HW),
-    "dn_head_1x1_backward");
-  DN_LAUNCH_CHECK();
   const int nblk = red_blocks((long)N * HW);
+  if (bn) {
+    if (int rc = bn_unit_check(*bn, x.channels, dtype, (long)N * HW, "dn_head_1x1_backward_bn_sums")) return rc;
+    DN_CHECK_ARG(nplanes < 65536, "dn_head_1x1_backward_bn_sums: too many planes for the launch grid");
+#define ARGS_H dlogits, w, (unsigned char*)g.base, g.planes_total, g.plane0, (const unsigned char*)bn->y.base, bn->y.planes_total, \
+               bn->y.plane0, bn->scale, bn->shift, bn->mean, bn->invstd, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), bn->sums, cpad
+    DN_DISPATCH_T(dtype,
+      hipLaunchKernelGGL(head_bwd_data_sums_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_H),
+      hipLaunchKernelGGL(head_bwd_data_sums_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, ARGS_H),
+      "dn_head_1x1_backward_bn_sums");
+#undef ARGS_H
+    *bn->nblk = nblk;
+  } else {
+    DN_DISPATCH_T(dtype,
+      hipLaunchKernelGGL(head_bwd_data_kernel<__bf16>, dim3(ew_grid(total)), dim3(256), 0, s, dlogits, w, (unsigned char*)g.base, g.planes_total, g.plane0, nplanes, (long)N, HW),
+      hipLaunchKernelGGL(head_bwd_data_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, s, dlogits, w, (unsigned char*)g.base, g.planes_total, g.plane0, nplanes, (long)N, HW),
+      "dn_head_1x1_backward");
+  }
+  DN_LAUNCH_CHECK();
   DN_DISPATCH_T(dtype,
     hipLaunchKernelGGL(channel_sum_kernel<__bf16>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), dlogits, partial, cpad),
     hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nblk, nplanes), dim3(RED_THREADS), 0, s, (const unsigned char*)x.base, x.planes_total, x.plane0, N, (int)(HW * 2), red_seg(N, nplanes, (int)(HW * 2)), dlogits, partial, cpad),

@@ -97,6 +97,10 @@ _SIGS = {
                                         c_long, POINTER(c_int), _P]),
     "dn_bn_train_backward_sums": (c_int, [DnTensor, DnTensor, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "dn_bn_backward_sums_totals": (c_int, [_P, c_int, c_int, _P, _P]),
+    "dn_maxpool_1x2_backward_bn_sums": (c_int, [DnTensor, DnTensor, DnTensor, DnTensor, DnTensor, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                                                _P, c_long, POINTER(c_int), _P]),
+    "dn_head_1x1_backward_bn_sums": (c_int, [_P, DnTensor, _P, DnTensor, _P, _P, _P, DnTensor, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                                             _P, c_long, POINTER(c_int), _P]),
     "dn_conv2d_stats": (c_int, [DnTensor, _P, _P, DnTensor, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_long, POINTER(c_int), _P]),
     "dn_bn_train_apply": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
                                   c_int, c_int, _P]),

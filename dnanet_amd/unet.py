@@ -702,6 +702,15 @@ class HipUNet(ParameterTree):
         with torch.cuda.stream(side):
             segment_hook(name)
 
+    def _bn_sums_buffer(self, channels: int, blocks: int = 512) -> torch.Tensor:
+        """Workspace for [blocks][channel_pad][2] BatchNorm backward sums (one producer -> one consumer at a time, in stream
+        order); the elementwise producers use at most 512 blocks."""
+        ws = self._workspace()
+        need = max(blocks, 512) * hip.channel_pad(channels) * 2
+        if ws.get("bnsums") is None or ws["bnsums"].numel() < need:
+            ws["bnsums"] = torch.empty(need, dtype=torch.float32, device=self.device)
+        return ws["bnsums"]
+
     def _unit_backward(self, u: ConvUnit, g, want_dgrad: bool, feeds: Optional[ConvUnit] = None, sums=None):
         """g: dL/d(output activation) in a buffer (overwritten with dL/dy). Returns dL/d(input) ref.
         ``feeds``: the unit whose activation is this unit's input -- the data gradient then forms that unit's BatchNorm
@@ -758,10 +767,7 @@ class HipUNet(ParameterTree):
         gin.bn_sums = None
         if feeds is not None and self.fuse_bn_sums and (kh, kw) == (3, 5) and feeds.cout == cin_stored:
             fv = self._saved[feeds.conv]
-            cp = hip.channel_pad(feeds.cout)
-            need = n * ((h + 2) // 3) * ((w + 127) // 128) * cp * 2       # tiles are at least 3 rows x 128 columns
-            if ws.get("bnsums") is None or ws["bnsums"].numel() < need:
-                ws["bnsums"] = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._bn_sums_buffer(feeds.cout, n * ((h + 2) // 3) * ((w + 127) // 128))   # tiles are at least 3 rows x 128 columns
             ntiles = ctypes.c_int(0)
             self._timed(lambda: self.conv_kernel_tag(u.cout, cin_stored, n, h, w) + "+bnsums:dgrad", flops,
                         lambda: hip.check(hip.lib.dn_conv2d_dgrad_bn_sums(
@@ -793,9 +799,21 @@ class HipUNet(ParameterTree):
             hip.check(hip.lib.dn_dice_backward(hip.ptr(S["logits"]), hip.ptr(S["targets"]), dlogits.numel(), hip.ptr(sums),
                                                hip.ptr(dlogits), hip.stream_ptr()))
         g = PlaneBuffer(n, self._pp(c[0]), h, w, dt, dev, arena=A)
-        hip.check(hip.lib.dn_head_1x1_backward(hip.ptr(dlogits), S["head_in"], hip.ptr(self._train_cache["head_w"]), g.ref(c[0]),
-                                               hip.ptr(self.grad("outputs.weight")), hip.ptr(self.grad("outputs.bias")),
-                                               hip.ptr(ws["partial"]), n, h, w, dt, hip.stream_ptr()))
+        # (the producers of an activation gradient form BatchNorm backward's sums of the unit it belongs to: _unit_backward)
+        last = units[f"decoders.{depth - 1}.conv.double_conv.3"]
+        head_sums = None
+        if self.fuse_bn_sums:
+            fv, sums, nblk = S[last.conv], self._bn_sums_buffer(last.cout), ctypes.c_int(0)
+            hip.check(hip.lib.dn_head_1x1_backward_bn_sums(
+                hip.ptr(dlogits), S["head_in"], hip.ptr(self._train_cache["head_w"]), g.ref(c[0]), hip.ptr(self.grad("outputs.weight")),
+                hip.ptr(self.grad("outputs.bias")), hip.ptr(ws["partial"]), fv["y"].ref(last.cout), hip.ptr(fv["scale"]),
+                hip.ptr(fv["shift"]), hip.ptr(fv["mean"]), hip.ptr(fv["invstd"]), n, h, w, dt, hip.ptr(sums), sums.numel(),
+                ctypes.byref(nblk), hip.stream_ptr()))
+            head_sums = (sums, nblk.value)
+        else:
+            hip.check(hip.lib.dn_head_1x1_backward(hip.ptr(dlogits), S["head_in"], hip.ptr(self._train_cache["head_w"]), g.ref(c[0]),
+                                                   hip.ptr(self.grad("outputs.weight")), hip.ptr(self.grad("outputs.bias")),
+                                                   hip.ptr(ws["partial"]), n, h, w, dt, hip.stream_ptr()))
         if segment_hook:
             self._segment_done(segment_hook, "head")
         gcat = [None] * depth
@@ -806,7 +824,8 @@ class HipUNet(ParameterTree):
         for i in reversed(range(depth)):
             l = depth - 1 - i
             pre = f"decoders.{i}.conv.double_conv"
-            g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True, feeds=units[pre + ".0"])
+            g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True, feeds=units[pre + ".0"],
+                                     sums=head_sums if i == depth - 1 else None)
             done(cur)
             gcat[l] = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), True, sums=g1.bn_sums)
             done(g1)
@@ -835,11 +854,21 @@ class HipUNet(ParameterTree):
             pre = f"encoders.{l}.conv.double_conv"
             skip = S["cat"][l].ref(c[l], self._pp(c[l]))
             g2 = PlaneBuffer(n, self._pp(c[l]), h, wl[l], dt, dev, arena=A)
-            hip.check(hip.lib.dn_maxpool_1x2_backward(skip, gpool.ref(c[l]), gcat[l].ref(c[l], self._pp(c[l])), g2.ref(c[l]), n, h,
-                                                      wl[l + 1], dt, hip.stream_ptr()))
+            pool_sums = None
+            if self.fuse_bn_sums:
+                u3 = units[pre + ".3"]
+                fv, sums, nblk = S[u3.conv], self._bn_sums_buffer(u3.cout), ctypes.c_int(0)
+                hip.check(hip.lib.dn_maxpool_1x2_backward_bn_sums(
+                    skip, gpool.ref(c[l]), gcat[l].ref(c[l], self._pp(c[l])), g2.ref(c[l]), fv["y"].ref(u3.cout), hip.ptr(fv["scale"]),
+                    hip.ptr(fv["shift"]), hip.ptr(fv["mean"]), hip.ptr(fv["invstd"]), n, h, wl[l + 1], dt, hip.ptr(sums), sums.numel(),
+                    ctypes.byref(nblk), hip.stream_ptr()))
+                pool_sums = (sums, nblk.value)
+            else:
+                hip.check(hip.lib.dn_maxpool_1x2_backward(skip, gpool.ref(c[l]), gcat[l].ref(c[l], self._pp(c[l])), g2.ref(c[l]), n, h,
+                                                          wl[l + 1], dt, hip.stream_ptr()))
             done(gpool)
             done(gcat[l])
-            g1 = self._unit_backward(units[pre + ".3"], g2.ref(c[l]), True, feeds=units[pre + ".0"])
+            g1 = self._unit_backward(units[pre + ".3"], g2.ref(c[l]), True, feeds=units[pre + ".0"], sums=pool_sums)
             done(g2)
             gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), l > 0, sums=g1.bn_sums)
             done(g1)

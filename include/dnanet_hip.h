@@ -254,6 +254,17 @@ int dn_maxpool_1x2_backward(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_te
  * db = sum dlogits. */
 int dn_head_1x1_backward(const float* dlogits, dn_tensor x, const float* w, dn_tensor g, float* dw, float* db, float* partial,
                          int N, int H, int W, int dtype, void* stream);
+/* dn_maxpool_1x2_backward / dn_head_1x1_backward together with the reduction pass of dn_bn_train_backward for the unit
+ * whose activation gradient g is (the second unit of an encoder block / of the last decoder block): besides g, per block
+ * and channel { sum dz, sum dz * xhat } over the values of g as stored -- sums[*nblk][dn_channel_pad(C)][2], at most
+ * dn_reduce_blocks(pixels) blocks; bn_y / scale / shift / mean / invstd as in dn_conv2d_dgrad_bn_sums.  Followed by
+ * dn_bn_train_backward_sums (or dn_bn_backward_sums_totals), g is read back one time less. */
+int dn_maxpool_1x2_backward_bn_sums(dn_tensor x, dn_tensor dpool, dn_tensor dskip, dn_tensor g, dn_tensor bn_y, const float* scale,
+                                    const float* shift, const float* mean, const float* invstd, int N, int H, int Wout, int dtype,
+                                    float* sums, long sums_floats, int* nblk, void* stream);
+int dn_head_1x1_backward_bn_sums(const float* dlogits, dn_tensor x, const float* w, dn_tensor g, float* dw, float* db, float* partial,
+                                 dn_tensor bn_y, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                 int N, int H, int W, int dtype, float* sums, long sums_floats, int* nblk, void* stream);
 /* out[c] = sum over (N,H,W) of x[c]: bias gradient of nn.ConvTranspose2d (unet_architecture.py:54-57). */
 int dn_channel_sum(dn_tensor x, float* out, float* partial, int N, int H, int W, int dtype, void* stream);
 /* Weight gradient of nn.Conv2d(cin, cout, (kh,kw), padding=k//2): dw[cout][cin][kh][kw] (canonical fp32, overwritten).

@@ -688,6 +688,101 @@ def test_maxpool_backward_with_skip(gpu_device, dtype):
     assert torch.equal(gb.to_nchw(c).cpu(), _q(ref, dtype))
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 24, 5, 64), (3, 32, 6, 200), (40, 64, 5, 512), (1, 8, 3, 34)])
+def test_pool_and_head_backward_with_bn_sums(gpu_device, dtype, shape):
+    """dn_maxpool_1x2_backward_bn_sums / dn_head_1x1_backward_bn_sums: g (and dw, db) bitwise those of the plain entry points,
+    and block sums whose totals are BatchNorm backward's reduction over the stored g: dn_bn_train_backward_sums on them gives
+    what dn_bn_train_backward gives on the same tensors."""
+    import ctypes
+    hip = _hip()
+    dev = gpu_device
+    n, c, h, w = shape
+    gen = torch.Generator().manual_seed(31 + dtype)
+    cp = hip.channel_pad(c)
+    # the BatchNorm unit whose activation gradient the producers write
+    y = torch.randn(n, c, h, w, generator=gen) * 2 + 0.5
+    yb = hip.PlaneBuffer.from_nchw(y.to(dev), dtype)
+    yq = yb.to_nchw(c).cpu().double()
+    vec = torch.full((4 * cp,), float("nan"), device=dev)
+    vs = [vec[i * cp:(i + 1) * cp] for i in range(4)]
+    scale, shift = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
+    mean, invstd = torch.randn(c, generator=gen), torch.rand(c, generator=gen) + 0.5
+    for dst, src in zip(vs, (scale, shift, mean, invstd)):
+        dst[:c] = src.to(dev)
+    bn = (yb.ref(c), hip.ptr(vs[0]), hip.ptr(vs[1]), hip.ptr(vs[2]), hip.ptr(vs[3]))
+    cap = 512 * cp * 2
+    part = torch.empty(max(hip.partial_floats(c), 4096), device=dev)
+    bc = lambda v: v.double().view(1, -1, 1, 1)
+
+    def check_sums(gbuf, sums, nblk):
+        gq = gbuf.to_nchw(c).cpu().double()
+        t = yq * bc(scale) + bc(shift)
+        safe = (t.abs() > 1e-4).double()        # elements whose sign cannot depend on the rounding of the fp32 fma
+        dz = gq * (t > 0)
+        xhat = (yq - bc(mean)) * bc(invstd)
+        want = torch.stack([dz.sum((0, 2, 3)), (dz * xhat).sum((0, 2, 3))], 1)
+        got = sums[:nblk * cp * 2].view(nblk, cp, 2).double().sum(0).cpu()[:c]
+        slack = float(((1 - safe) * gq.abs() * (1 + xhat.abs())).sum((0, 2, 3)).max())
+        assert torch.allclose(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()) + slack), float((got - want).abs().max())
+        gamma = (torch.rand(c, generator=gen) + 0.5).to(dev)
+        outs = []
+        for fused in (False, True):
+            gb2 = hip.PlaneBuffer(n, hip.planes(c, dtype), h, w, dtype, dev, zero=True)
+            gb2.data.copy_(gbuf.data)
+            dgam, dbet, coef = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(3 * cp, device=dev)
+            common = (gb2.ref(c), yb.ref(c), hip.ptr(vs[0]), hip.ptr(vs[1]), n, h, w, hip.ptr(gamma), hip.ptr(vs[2]), hip.ptr(vs[3]),
+                      hip.ptr(dgam), hip.ptr(dbet), hip.ptr(coef))
+            if fused:
+                hip.check(hip.lib.dn_bn_train_backward_sums(*common, hip.ptr(sums), nblk, dtype, hip.stream_ptr()))
+            else:
+                hip.check(hip.lib.dn_bn_train_backward(*common, hip.ptr(part), dtype, hip.stream_ptr()))
+            torch.cuda.synchronize()
+            outs.append((gb2.to_nchw(c).cpu(), dgam.cpu(), dbet.cpu()))
+        tol = 1e-5 if dtype == 0 else 1e-2
+        for u, v in zip(*outs):
+            assert torch.allclose(u, v, rtol=tol, atol=tol * float(v.abs().max()))
+
+    # ---- pooling backward + skip gradient
+    if w % 2 == 0:
+        x = torch.randint(-2, 3, (n, c, h, w), generator=gen).float()
+        dpool, dskip = torch.randn(n, c, h, w // 2, generator=gen), torch.randn(n, c, h, w, generator=gen)
+        xb, dpb, dsb = (hip.PlaneBuffer.from_nchw(t.to(dev), dtype) for t in (x, dpool, dskip))
+        for with_skip in (True, False):
+            ds = dsb.ref(c) if with_skip else hip.DnTensor(None, 0, 0, c)
+            plain = hip.PlaneBuffer(n, hip.planes(c, dtype), h, w, dtype, dev, zero=True)
+            hip.check(hip.lib.dn_maxpool_1x2_backward(xb.ref(c), dpb.ref(c), ds, plain.ref(c), n, h, w // 2, dtype, hip.stream_ptr()))
+            gb = hip.PlaneBuffer(n, hip.planes(c, dtype), h, w, dtype, dev, zero=True)
+            sums, nblk = torch.full((cap,), float("nan"), device=dev), ctypes.c_int(0)
+            hip.check(hip.lib.dn_maxpool_1x2_backward_bn_sums(xb.ref(c), dpb.ref(c), ds, gb.ref(c), *bn, n, h, w // 2, dtype, hip.ptr(sums),
+                                                              cap, ctypes.byref(nblk), hip.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(gb.data, plain.data) and 0 < nblk.value <= 512
+            check_sums(gb, sums, nblk.value)
+        assert hip.lib.dn_maxpool_1x2_backward_bn_sums(xb.ref(c), dpb.ref(c), dsb.ref(c), gb.ref(c), *bn, n, h, w // 2, dtype, hip.ptr(sums),
+                                                       8, ctypes.byref(nblk), hip.stream_ptr()) != 0
+    # ---- head backward
+    dlog = torch.randn(n, 1, h, w, generator=gen).to(dev)
+    act = hip.PlaneBuffer.from_nchw(torch.randn(n, c, h, w, generator=gen).to(dev), dtype)
+    hw_ = _padvec(torch.randn(c, generator=gen), cp, dev)
+    res = []
+    for fused in (False, True):
+        gb = hip.PlaneBuffer(n, hip.planes(c, dtype), h, w, dtype, dev, zero=True)
+        dw, db = torch.zeros(c, device=dev), torch.zeros(1, device=dev)
+        sums, nblk = torch.full((cap,), float("nan"), device=dev), ctypes.c_int(0)
+        if fused:
+            hip.check(hip.lib.dn_head_1x1_backward_bn_sums(hip.ptr(dlog), act.ref(c), hip.ptr(hw_), gb.ref(c), hip.ptr(dw), hip.ptr(db),
+                                                           hip.ptr(part), *bn, n, h, w, dtype, hip.ptr(sums), cap, ctypes.byref(nblk),
+                                                           hip.stream_ptr()))
+        else:
+            hip.check(hip.lib.dn_head_1x1_backward(hip.ptr(dlog), act.ref(c), hip.ptr(hw_), gb.ref(c), hip.ptr(dw), hip.ptr(db),
+                                                   hip.ptr(part), n, h, w, dtype, hip.stream_ptr()))
+        torch.cuda.synchronize()
+        res.append((gb, dw.clone(), db.clone(), sums, nblk.value))
+    assert torch.equal(res[0][0].data, res[1][0].data) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    check_sums(res[1][0], res[1][3], res[1][4])
+
+
 def test_dice_and_adam(gpu_device):
     hip = _hip()
     g = torch.Generator().manual_seed(8)
