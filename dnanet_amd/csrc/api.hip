@@ -56,7 +56,8 @@ static int run_igemm(const ConvParams& p, int kh, int kw, int dtype, hipStream_t
   const ConvVariant v = choose_variant(p, kh, kw, dtype);
   const int ht = v.ht, cot = v.cot;
   if (p.bn_y) {                      // data gradient + BatchNorm backward sums of the unit it feeds
-    if (!(kh == 3 && kw == 5)) return dn_set_error(DN_ERR_UNSUPPORTED, "BatchNorm-sums epilogue: kernel size (%d,%d) is not built (have (3,5))", kh, kw);
+    if (kh == 1 && kw == 1) return dtype == DN_BF16 ? conv_igemm_run_bf16_k11_bnred(p, ht, cot, s) : conv_igemm_run_f32_k11_bnred(p, ht, cot, s);
+    if (!(kh == 3 && kw == 5)) return dn_set_error(DN_ERR_UNSUPPORTED, "BatchNorm-sums epilogue: kernel size (%d,%d) is not built (have (3,5), (1,1))", kh, kw);
     if (p.bias || p.relu || p.y_wmul != 1 || !p.stats) return dn_set_error(DN_ERR_ARG, "BatchNorm-sums epilogue: a plain data gradient only");
     if (v.wave8) return dtype == DN_BF16 ? conv_igemm8_run_bf16_bnred(p, ht, s) : conv_igemm8_run_f32_bnred(p, ht, s);
     return dtype == DN_BF16 ? conv_igemm_run_bf16_k35_bnred(p, ht, cot, s) : conv_igemm_run_f32_k35_bnred(p, ht, cot, s);
@@ -203,8 +204,29 @@ int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2,
   return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);
 }
 
+static int conv_transpose_dgrad_impl(dn_tensor dy, const void* packed_w, dn_tensor dx, int N, int H, int Win, int dtype, void* stream,
+                                     const BnSums* bn, float* sums, long sums_floats, int* ntiles);
+
 int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx, int N, int H, int Win, int dtype,
                                 void* stream) {
+  return conv_transpose_dgrad_impl(dy, packed_w, dx, N, H, Win, dtype, stream, nullptr, nullptr, 0, nullptr);
+}
+
+int dn_conv_transpose_1x2_dgrad_bn_sums(dn_tensor dy, const void* packed_w, dn_tensor dx, dn_tensor bn_y, const float* scale,
+                                        const float* shift, const float* mean, const float* invstd, int N, int H, int Win, int dtype,
+                                        float* sums, long sums_floats, int* ntiles, void* stream) {
+  DN_CHECK_ARG(sums && ntiles && bn_y.base && scale && shift && mean && invstd, "dn_conv_transpose_1x2_dgrad_bn_sums: null pointer");
+  DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_transpose_1x2_dgrad_bn_sums: bad dtype %d", dtype);
+  DN_CHECK_ARG(bn_y.channels == dx.channels, "dn_conv_transpose_1x2_dgrad_bn_sums: bn_y has %d channels, dx %d", bn_y.channels, dx.channels);
+  const int bp = dn_planes(bn_y.channels, dtype);
+  DN_CHECK_ARG(bn_y.plane0 >= 0 && bn_y.plane0 + bp <= bn_y.planes_total, "dn_conv_transpose_1x2_dgrad_bn_sums: bn_y planes [%d,%d) outside buffer of %d",
+               bn_y.plane0, bn_y.plane0 + bp, bn_y.planes_total);
+  const BnSums bn{bn_y, scale, shift, mean, invstd};
+  return conv_transpose_dgrad_impl(dy, packed_w, dx, N, H, Win, dtype, stream, &bn, sums, sums_floats, ntiles);
+}
+
+static int conv_transpose_dgrad_impl(dn_tensor dy, const void* packed_w, dn_tensor dx, int N, int H, int Win, int dtype, void* stream,
+                                     const BnSums* bn, float* sums, long sums_floats, int* ntiles) {
   DN_CHECK_ARG(dy.base && packed_w && dx.base, "dn_conv_transpose_1x2_dgrad: null pointer");
   DN_CHECK_ARG(N > 0 && H > 0 && Win > 0, "dn_conv_transpose_1x2_dgrad: bad shape");
   DN_CHECK_ARG(dtype == DN_BF16 || dtype == DN_F32, "dn_conv_transpose_1x2_dgrad: bad dtype %d", dtype);
@@ -218,6 +240,16 @@ int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx
   p.y = dx.base; p.y_planes_total = dx.planes_total; p.y_plane0 = dx.plane0; p.y_nplanes = xp; p.y_gplanes = 1 << 30; p.y_wmul = 1;
   p.N = N; p.H = H; p.W = Win; p.nchunk = 2 * (gsize / epr); p.cout_pad = dn_channel_pad(dx.channels); p.relu = 0;
   flatten_rows(p);
+  if (bn) {        // (the unit's saved convolution output has dx's pixel grid, so the flattened rows address it as well)
+    p.bn_y = bn->y.base; p.bn_planes_total = bn->y.planes_total; p.bn_plane0 = bn->y.plane0;
+    p.bn_scale = bn->scale; p.bn_shift = bn->shift; p.bn_mean = bn->mean; p.bn_invstd = bn->invstd;
+    p.stats = sums;
+    const ConvVariant v = choose_variant(p, 1, 1, dtype);
+    const long tiles = (long)N * ((p.H + v.ht - 1) / v.ht) * ((p.W + 127) / 128);
+    DN_CHECK_ARG(tiles * p.cout_pad * 2 <= sums_floats, "dn_conv_transpose_1x2_dgrad_bn_sums: sums buffer of %ld floats, need %ld",
+                 sums_floats, tiles * p.cout_pad * 2);
+    *ntiles = (int)tiles;
+  }
   return run_igemm(p, 1, 1, dtype, (hipStream_t)stream);
 }
 

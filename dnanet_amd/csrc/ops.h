@@ -13,6 +13,8 @@ int conv_igemm_run_bf16_k11_split(const ConvParams& p, int ht, int cot, hipStrea
 int conv_igemm_run_f32_k35(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_bf16_k35_bnred(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k35_bnred(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_bf16_k11_bnred(const ConvParams& p, int ht, int cot, hipStream_t s);
+int conv_igemm_run_f32_k11_bnred(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k13(const ConvParams& p, int ht, int cot, hipStream_t s);
 int conv_igemm_run_f32_k11(const ConvParams& p, int ht, int cot, hipStream_t s);
 

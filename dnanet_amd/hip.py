@@ -58,6 +58,8 @@ _SIGS = {
     "dn_conv2d": (c_int, [DnTensor, _P, _P, DnTensor] + [c_int] * 7 + [_P]),
     "dn_conv_transpose_1x2": (c_int, [DnTensor, _P, _P, DnTensor, c_int, c_int, c_int, c_int, _P]),
     "dn_conv_transpose_1x2_dgrad": (c_int, [DnTensor, _P, DnTensor, c_int, c_int, c_int, c_int, _P]),
+    "dn_conv_transpose_1x2_dgrad_bn_sums": (c_int, [DnTensor, _P, DnTensor, DnTensor, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_long,
+                                                    POINTER(c_int), _P]),
     "dn_maxpool_1x2": (c_int, [DnTensor, DnTensor, c_int, c_int, c_int, c_int, _P]),
     "dn_head_1x1": (c_int, [DnTensor, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "dn_reduce_blocks": (c_int, [c_long]),

@@ -82,6 +82,7 @@ class HipUNet(ParameterTree):
         self.overlap_wgrad = self.flat_params.is_cuda and not os.environ.get("DN_TUNE_NO_WGRAD_STREAM")
         # BatchNorm backward's sums in the epilogue of the data gradient that produces the unit's activation gradient
         self.fuse_bn_sums = not os.environ.get("DN_TUNE_NO_BN_SUMS")
+        self.fuse_bn_sums_convt = not os.environ.get("DN_TUNE_NO_BN_SUMS_CONVT")   # ... of the transposed convolution's data gradient
         self._wgrad_stream = None
         self.two_stream_max_pixels = 20_000_000       # N*H*W above which backward stays on one stream (see _side)
         # Device memory of the passes: one StepArena per (kind of pass, batch shape), allocated by the first pass at that
@@ -801,7 +802,7 @@ class HipUNet(ParameterTree):
         g = PlaneBuffer(n, self._pp(c[0]), h, w, dt, dev, arena=A)
         # (the producers of an activation gradient form BatchNorm backward's sums of the unit it belongs to: _unit_backward)
         last = units[f"decoders.{depth - 1}.conv.double_conv.3"]
-        head_sums = None
+        up_sums = None                      # sums of the unit the next _unit_backward call handles, from its producer
         if self.fuse_bn_sums:
             fv, sums, nblk = S[last.conv], self._bn_sums_buffer(last.cout), ctypes.c_int(0)
             hip.check(hip.lib.dn_head_1x1_backward_bn_sums(
@@ -809,7 +810,7 @@ class HipUNet(ParameterTree):
                 hip.ptr(self.grad("outputs.bias")), hip.ptr(ws["partial"]), fv["y"].ref(last.cout), hip.ptr(fv["scale"]),
                 hip.ptr(fv["shift"]), hip.ptr(fv["mean"]), hip.ptr(fv["invstd"]), n, h, w, dt, hip.ptr(sums), sums.numel(),
                 ctypes.byref(nblk), hip.stream_ptr()))
-            head_sums = (sums, nblk.value)
+            up_sums = (sums, nblk.value)
         else:
             hip.check(hip.lib.dn_head_1x1_backward(hip.ptr(dlogits), S["head_in"], hip.ptr(self._train_cache["head_w"]), g.ref(c[0]),
                                                    hip.ptr(self.grad("outputs.weight")), hip.ptr(self.grad("outputs.bias")),
@@ -824,8 +825,7 @@ class HipUNet(ParameterTree):
         for i in reversed(range(depth)):
             l = depth - 1 - i
             pre = f"decoders.{i}.conv.double_conv"
-            g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True, feeds=units[pre + ".0"],
-                                     sums=head_sums if i == depth - 1 else None)
+            g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[l]), True, feeds=units[pre + ".0"], sums=up_sums)
             done(cur)
             gcat[l] = self._unit_backward(units[pre + ".0"], g1.ref(c[l]), True, sums=g1.bn_sums)
             done(g1)
@@ -838,13 +838,25 @@ class HipUNet(ParameterTree):
             hip.check(hip.lib.dn_channel_sum(d_up, hip.ptr(self.grad(upn + ".bias")), hip.ptr(ws["partial"]), n, h, wl[l], dt,
                                              hip.stream_ptr()))
             gx = PlaneBuffer(n, self._pp(c[l + 1]), h, wl[l + 1], dt, dev, arena=A)
-            hip.check(hip.lib.dn_conv_transpose_1x2_dgrad(d_up, hip.ptr(self._train_cache[upn]["wd"]), gx.ref(c[l + 1]), n, h,
-                                                          wl[l + 1], dt, hip.stream_ptr()))
+            # gx is the activation gradient of the second unit of the block below (previous decoder, or the bottleneck)
+            below = units[(f"decoders.{i - 1}.conv" if i > 0 else "bottleneck") + ".double_conv.3"]
+            up_sums = None
+            if self.fuse_bn_sums and self.fuse_bn_sums_convt:
+                fv, nt = S[below.conv], ctypes.c_int(0)
+                sums = self._bn_sums_buffer(below.cout, n * ((h * wl[l + 1] + 127) // 128 + h))
+                hip.check(hip.lib.dn_conv_transpose_1x2_dgrad_bn_sums(
+                    d_up, hip.ptr(self._train_cache[upn]["wd"]), gx.ref(c[l + 1]), fv["y"].ref(below.cout), hip.ptr(fv["scale"]),
+                    hip.ptr(fv["shift"]), hip.ptr(fv["mean"]), hip.ptr(fv["invstd"]), n, h, wl[l + 1], dt, hip.ptr(sums), sums.numel(),
+                    ctypes.byref(nt), hip.stream_ptr()))
+                up_sums = (sums, nt.value)
+            else:
+                hip.check(hip.lib.dn_conv_transpose_1x2_dgrad(d_up, hip.ptr(self._train_cache[upn]["wd"]), gx.ref(c[l + 1]), n, h,
+                                                              wl[l + 1], dt, hip.stream_ptr()))
             cur = gx
             if segment_hook:
                 self._segment_done(segment_hook, f"decoders.{i}")
         pre = "bottleneck.double_conv"
-        g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[depth]), True, feeds=units[pre + ".0"])
+        g1 = self._unit_backward(units[pre + ".3"], cur.ref(c[depth]), True, feeds=units[pre + ".0"], sums=up_sums)
         done(cur)
         gpool = self._unit_backward(units[pre + ".0"], g1.ref(c[depth]), True, sums=g1.bn_sums)
         done(g1)

@@ -117,6 +117,12 @@ int dn_conv_transpose_1x2(dn_tensor x, const void* packed_w, const float* bias2,
  * DN_PACK_CONVT_DGRAD. */
 int dn_conv_transpose_1x2_dgrad(dn_tensor dy, const void* packed_w, dn_tensor dx, int N, int H, int Win, int dtype,
                                 void* stream);
+/* dn_conv_transpose_1x2_dgrad together with the reduction pass of dn_bn_train_backward for the unit whose activation the
+ * transposed convolution reads (the second unit of the block below): as dn_conv2d_dgrad_bn_sums, dx being that unit's
+ * activation gradient.  sums[*ntiles][dn_channel_pad(C)][2]. */
+int dn_conv_transpose_1x2_dgrad_bn_sums(dn_tensor dy, const void* packed_w, dn_tensor dx, dn_tensor bn_y, const float* scale,
+                                        const float* shift, const float* mean, const float* invstd, int N, int H, int Win, int dtype,
+                                        float* sums, long sums_floats, int* ntiles, void* stream);
 /* ---- bf16x3: the same eval-mode operators on hi + lo split bf16 tensors and weights ----------------
  * fp32-grade results from the bf16 matrix cores: a product w*x is evaluated as w_hi*x_hi + w_hi*x_lo + w_lo*x_hi (three
  * bf16 MFMAs, fp32 accumulation; the dropped w_lo*x_lo term is 2^-18 relative), and every activation is written back as

@@ -400,6 +400,33 @@ def test_conv_transpose(gpu_device, case, dtype):
                                                   hip.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(dxb.to_nchw(cin).cpu(), _q(refdx, dtype))
+    # the same with BatchNorm backward's sums of the unit whose activation the transposed convolution read
+    import ctypes
+    dev = gpu_device
+    y = torch.randint(-4, 5, (n, cin, h, win), generator=g).float()
+    yb2 = hip.PlaneBuffer.from_nchw(y.to(dev), dtype)
+    cp = hip.channel_pad(cin)
+    pick = lambda vals: torch.tensor(vals)[torch.randint(0, len(vals), (cin,), generator=g)]
+    scale, shift = pick([-2.0, -1.0, -0.5, 0.5, 1.0, 2.0]), torch.randint(-3, 4, (cin,), generator=g).float() + 0.25
+    mean, invstd = torch.randint(-4, 5, (cin,), generator=g).float() * 0.5, pick([0.5, 1.0, 2.0])
+    vec = torch.full((4 * cp,), float("nan"), device=dev)
+    vs = [vec[i * cp:(i + 1) * cp] for i in range(4)]
+    for dst, src in zip(vs, (scale, shift, mean, invstd)):
+        dst[:cin] = src.to(dev)
+    cap = n * ((h * win + 127) // 128 + h) * cp * 2
+    sums, nt = torch.full((cap,), float("nan"), device=dev), ctypes.c_int(0)
+    dxs = hip.PlaneBuffer(n, hip.planes(cin, dtype), h, win, dtype, dev, zero=True)
+    args = (dyb.ref(cout), hip.ptr(packed_d), dxs.ref(cin), yb2.ref(cin), hip.ptr(vs[0]), hip.ptr(vs[1]), hip.ptr(vs[2]), hip.ptr(vs[3]),
+            n, h, win, dtype, hip.ptr(sums))
+    hip.check(hip.lib.dn_conv_transpose_1x2_dgrad_bn_sums(*args, cap, ctypes.byref(nt), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dxs.data, dxb.data) and 0 < nt.value and nt.value * cp * 2 <= cap
+    got = sums[:nt.value * cp * 2].view(nt.value, cp, 2).double().sum(0).cpu()[:cin]
+    bc = lambda v: v.double().view(1, -1, 1, 1)
+    dz = dxs.to_nchw(cin).cpu().double() * ((y.double() * bc(scale) + bc(shift)) > 0)
+    want = torch.stack([dz.sum((0, 2, 3)), (dz * (y.double() - bc(mean)) * bc(invstd)).sum((0, 2, 3))], 1)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    assert hip.lib.dn_conv_transpose_1x2_dgrad_bn_sums(*args, 16, ctypes.byref(nt), hip.stream_ptr()) != 0
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
