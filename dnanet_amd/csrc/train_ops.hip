@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void pool_bwd_add_kernel(const unsigned char* 
 // the unit's reduction pass over g and y is not needed (bn_bwd_reduce_kernel's arithmetic and partial layout; work split
 // as there: (image, segment) units of a plane dealt round-robin to the blocks, a thread's piece parity fixed).
 // An item = one pooled pixel x one 16-byte piece: two neighbouring full-resolution records.
+constexpr int POOL_ILP = 2;          // items in flight per thread of pool_bwd_add_sums_kernel / head_bwd_data_sums_kernel
 template <typename T>
 __global__ __launch_bounds__(RED_THREADS) void pool_bwd_add_sums_kernel(
     const unsigned char* x, int x_pt, int x_p0, const unsigned char* dpool, int dp_pt, int dp_p0, const unsigned char* dskip,
@@ -460,34 +461,46 @@ __global__ __launch_bounds__(RED_THREADS) void pool_bwd_add_sums_kernel(
     unsigned char* gb = g + ((long)n * g_pt + g_p0 + plane) * nitems * 32;
     const unsigned char* pb = dpool + ((long)n * dp_pt + dp_p0 + plane) * nitems * 16;
     const int iend = min(nitems, (seg + 1) * seg_len);
-    for (int i = seg * seg_len + threadIdx.x; i < iend; i += RED_THREADS) {
-      const long full = (long)(i >> 1) * 64 + 16 * pc;      // byte offset of the even column's piece; the odd one is 32 further
-      float x0[PN], x1[PN], dp[PN], s0[PN] = {}, s1[PN] = {}, y0[PN], y1[PN];
-      const uint4 vx0 = *(const uint4*)(xb + full), vx1 = *(const uint4*)(xb + full + 32);
-      const uint4 vdp = *(const uint4*)(pb + (long)i * 16);
-      const uint4 vy0 = *(const uint4*)(yb + full), vy1 = *(const uint4*)(yb + full + 32);
-      if (sb) {
-        Piece<T>::unpack(*(const uint4*)(sb + full), s0);
-        Piece<T>::unpack(*(const uint4*)(sb + full + 32), s1);
-      }
-      Piece<T>::unpack(vx0, x0); Piece<T>::unpack(vx1, x1); Piece<T>::unpack(vdp, dp);
-      Piece<T>::unpack(vy0, y0); Piece<T>::unpack(vy1, y1);
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += POOL_ILP * RED_THREADS) {
+      // POOL_ILP items' loads (7 pieces each) are issued before the first is used
+      uint4 vx0[POOL_ILP], vx1[POOL_ILP], vdp[POOL_ILP], vy0[POOL_ILP], vy1[POOL_ILP], vs0[POOL_ILP], vs1[POOL_ILP];
 #pragma unroll
-      for (int j = 0; j < PN; ++j) {
-        const bool first = x0[j] >= x1[j];       // ties go to the first element (ATen max_pool2d backward)
-        s0[j] += first ? dp[j] : 0.f;
-        s1[j] += first ? 0.f : dp[j];
+      for (int k = 0; k < POOL_ILP; ++k) {
+        const int ii = i + k * RED_THREADS < iend ? i + k * RED_THREADS : i;   // past the end: item i again (loaded, not used)
+        const long full = (long)(ii >> 1) * 64 + 16 * pc;      // byte offset of the even column's piece; the odd one is 32 further
+        vx0[k] = *(const uint4*)(xb + full); vx1[k] = *(const uint4*)(xb + full + 32);
+        vdp[k] = *(const uint4*)(pb + (long)ii * 16);
+        vy0[k] = *(const uint4*)(yb + full); vy1[k] = *(const uint4*)(yb + full + 32);
+        vs0[k] = sb ? *(const uint4*)(sb + full) : make_uint4(0, 0, 0, 0);
+        vs1[k] = sb ? *(const uint4*)(sb + full + 32) : make_uint4(0, 0, 0, 0);
       }
-      const uint4 g0 = Piece<T>::pack(s0), g1 = Piece<T>::pack(s1);
-      *(uint4*)(gb + full) = g0;
-      *(uint4*)(gb + full + 32) = g1;
-      Piece<T>::unpack(g0, s0); Piece<T>::unpack(g1, s1);          // the gradient as stored
 #pragma unroll
-      for (int j = 0; j < PN; ++j) {
-        const float dz0 = fmaf(y0[j], sc[j], sh[j]) > 0.f ? s0[j] : 0.f;
-        const float dz1 = fmaf(y1[j], sc[j], sh[j]) > 0.f ? s1[j] : 0.f;
-        acc[0][j] += dz0 + dz1;
-        acc[1][j] = fmaf(dz1, (y1[j] - mu[j]) * is[j], fmaf(dz0, (y0[j] - mu[j]) * is[j], acc[1][j]));
+      for (int k = 0; k < POOL_ILP; ++k) {
+        const int ii = i + k * RED_THREADS;
+        if (ii < iend) {
+          const long full = (long)(ii >> 1) * 64 + 16 * pc;
+          float x0[PN], x1[PN], dp[PN], s0[PN], s1[PN], y0[PN], y1[PN];
+          Piece<T>::unpack(vs0[k], s0); Piece<T>::unpack(vs1[k], s1);       // (all-zero bits are 0.0 in both storage types)
+          Piece<T>::unpack(vx0[k], x0); Piece<T>::unpack(vx1[k], x1); Piece<T>::unpack(vdp[k], dp);
+          Piece<T>::unpack(vy0[k], y0); Piece<T>::unpack(vy1[k], y1);
+#pragma unroll
+          for (int j = 0; j < PN; ++j) {
+            const bool first = x0[j] >= x1[j];       // ties go to the first element (ATen max_pool2d backward)
+            s0[j] += first ? dp[j] : 0.f;
+            s1[j] += first ? 0.f : dp[j];
+          }
+          const uint4 g0 = Piece<T>::pack(s0), g1 = Piece<T>::pack(s1);
+          *(uint4*)(gb + full) = g0;
+          *(uint4*)(gb + full + 32) = g1;
+          Piece<T>::unpack(g0, s0); Piece<T>::unpack(g1, s1);          // the gradient as stored
+#pragma unroll
+          for (int j = 0; j < PN; ++j) {
+            const float dz0 = fmaf(y0[j], sc[j], sh[j]) > 0.f ? s0[j] : 0.f;
+            const float dz1 = fmaf(y1[j], sc[j], sh[j]) > 0.f ? s1[j] : 0.f;
+            acc[0][j] += dz0 + dz1;
+            acc[1][j] = fmaf(dz1, (y1[j] - mu[j]) * is[j], fmaf(dz0, (y0[j] - mu[j]) * is[j], acc[1][j]));
+          }
+        }
       }
     }
   }
@@ -536,20 +549,33 @@ __global__ __launch_bounds__(RED_THREADS) void head_bwd_data_sums_kernel(
     const unsigned char* yb = y + ((long)n * y_pt + y_p0 + plane) * npieces * 16;
     const float* dl = dlogit + (long)n * (npieces >> 1);
     const int iend = min(npieces, (seg + 1) * seg_len);
-    for (int i = seg * seg_len + threadIdx.x; i < iend; i += RED_THREADS) {
-      const float d = dl[i >> 1];
-      float f[PN], fy[PN];
-      Piece<T>::unpack(*(const uint4*)(yb + (long)i * 16), fy);
+    for (int i = seg * seg_len + threadIdx.x; i < iend; i += POOL_ILP * RED_THREADS) {
+      uint4 vy[POOL_ILP]; float d[POOL_ILP];
 #pragma unroll
-      for (int j = 0; j < PN; ++j) f[j] = d * wv[j];
-      const uint4 gv = Piece<T>::pack(f);
-      *(uint4*)(gb + (long)i * 16) = gv;
-      Piece<T>::unpack(gv, f);                                       // the gradient as stored
+      for (int k = 0; k < POOL_ILP; ++k) {
+        const int ii = i + k * RED_THREADS;
+        const bool in = ii < iend;
+        vy[k] = in ? *(const uint4*)(yb + (long)ii * 16) : make_uint4(0, 0, 0, 0);
+        d[k] = in ? dl[ii >> 1] : 0.f;
+      }
 #pragma unroll
-      for (int j = 0; j < PN; ++j) {
-        const float dz = fmaf(fy[j], sc[j], sh[j]) > 0.f ? f[j] : 0.f;
-        acc[0][j] += dz;
-        acc[1][j] = fmaf(dz, (fy[j] - mu[j]) * is[j], acc[1][j]);
+      for (int k = 0; k < POOL_ILP; ++k) {
+        const int ii = i + k * RED_THREADS;
+        if (ii < iend) {
+          float f[PN], fy[PN];
+          Piece<T>::unpack(vy[k], fy);
+#pragma unroll
+          for (int j = 0; j < PN; ++j) f[j] = d[k] * wv[j];
+          const uint4 gv = Piece<T>::pack(f);
+          *(uint4*)(gb + (long)ii * 16) = gv;
+          Piece<T>::unpack(gv, f);                                       // the gradient as stored
+#pragma unroll
+          for (int j = 0; j < PN; ++j) {
+            const float dz = fmaf(fy[j], sc[j], sh[j]) > 0.f ? f[j] : 0.f;
+            acc[0][j] += dz;
+            acc[1][j] = fmaf(dz, (fy[j] - mu[j]) * is[j], acc[1][j]);
+          }
+        }
       }
     }
   }
