@@ -94,7 +94,7 @@ static void flatten_rows(ConvParams& p) {
 extern "C" {
 
 const char* dn_last_error(void) { return g_err; }
-int dn_abi_version(void) { return 3; }
+int dn_abi_version(void) { return 4; }   // 4: the *_bn_sums entry points (round 3)
 
 int dn_conv2d_variant(int cin, int cout, int N, int H, int W, int kh, int kw, int dtype, char* buf, int buf_len) {
   DN_CHECK_ARG(buf && buf_len > 0, "dn_conv2d_variant: no buffer");

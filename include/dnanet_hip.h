@@ -61,7 +61,7 @@ typedef struct dn_tensor_x3 {
 #define DN_STATUS_HIP_ERROR 3
 
 const char* dn_last_error(void);
-int dn_abi_version(void);
+int dn_abi_version(void);   /* 4 since the *_bn_sums entry points were added; entry points are only ever added */
 static inline int dn_channel_pad(int c) { return (c + 31) / 32 * 32; }
 static inline int dn_planes(int c, int dtype) { int e = dtype == DN_DTYPE_BF16 ? 16 : 8; return (c + e - 1) / e; }
 

@@ -177,4 +177,4 @@ def test_c_abi_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(hip.lib, sym), f"{sym} declared in include/dnanet_hip.h but not exported"
     assert declared == set(hip.exported_symbols())
-    assert hip.lib.dn_abi_version() == 3
+    assert hip.lib.dn_abi_version() == 4
