@@ -280,7 +280,7 @@ def test_conv2d_dgrad(gpu_device, case, dtype):
 BN_SUMS_CASES = [
     # n, cin (channels of dx = of the BatchNorm unit), cout (channels of dy), h, w -> the tile the dispatcher picks
     (2, 32, 32, 5, 64), (3, 24, 16, 6, 200), (2, 72, 64, 5, 300), (1, 128, 32, 3, 128), (2, 64, 64, 6, 130), (2, 32, 64, 6, 256),
-    (130, 32, 32, 5, 512), (2, 8, 8, 7, 96),
+    (130, 32, 32, 5, 512), (2, 8, 8, 7, 96), (2, 130, 70, 4, 33), (3, 5, 3, 7, 257), (1, 40, 200, 2, 129), (2, 3, 2, 1, 7),
     (8, 512, 64, 5, 2048), (8, 512, 64, 6, 2048),                  # 8-wave kernels (fp32: both; bf16: the 5-row one)
 ]
 
